@@ -1,0 +1,464 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by IMPORTING the Python reference (read-only, /root/reference).
+
+Run in the build container only:   python tests/golden/gen_golden.py
+The reference never travels to the GPU box; only the .npz files written next to this script do.
+Every case records (a) the exact torch CPU draws the reference consumed (torch.randn / torch.rand_like, in call order),
+(b) the tensors the reference produced (paths, coefficients, cashflows, exposures, metric values, AAD gradients).
+Our oracle / HIP path replay the draws ("inject-Z") and must reproduce (b).
+
+Reference entry points exercised (file:line):
+  engine/engine.py:27-123, models/*.py step functions, controller/controller.py:272-383 (LSM), :385-471 (evaluation),
+  metrics/*.py, products/netting_set.py:48-184.
+"""
+import os
+import sys
+
+sys.dont_write_bytecode = True
+REF = os.environ.get("MCX_REFERENCE", "/root/reference")
+sys.path.insert(0, os.path.join(REF, "src"))
+
+import numpy as np
+import torch
+
+from common.enums import SimulationScheme
+from controller.controller import SimulationController
+from engine.engine import MonteCarloEngine
+from metrics.ce_metric import CEMetric
+from metrics.cva_metric import CVAMetric
+from metrics.eepe_metric import EEPEMetric
+from metrics.ene_metric import ENEMetric
+from metrics.epe_metric import EPEMetric
+from metrics.pfe_metric import PFEMetric
+from metrics.pv_metric import PVMetric
+from metrics.risk_metrics import RiskMetrics
+from models.black_scholes import BlackScholesModel
+from models.cirpp import CIRPPModel
+from models.heston import HestonModel
+from models.model_config import ModelConfig
+from models.vasicek import VasicekModel
+from products.bermudan_option import AmericanOption, BermudanOption
+from products.bond import Bond
+from products.equity import Equity
+from products.european_option import EuropeanOption, OptionType
+from products.netting_set import NettingSet
+from products.swap import InterestRateSwap, IRSType
+from request_interface.request_types import AtomicRequest, AtomicRequestType
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+F64 = torch.float64
+
+HAZARDS = {
+    0.5: 0.006402303360855854, 1.0: 0.01553038972325307, 2.0: 0.009729741230773657,
+    3.0: 0.015552544648116201, 4.0: 0.021196186202801115, 5.0: 0.02284319986706472,
+    7.0: 0.010111423894480876, 10.0: 0.00613267811172937, 15.0: 0.0036969930706003337,
+    20.0: 0.003791311459217732,
+}
+
+
+# ----------------------------------------------------------------------------------------------
+# draw recorder: wraps torch.randn / torch.rand_like while a reference run is in progress
+# ----------------------------------------------------------------------------------------------
+class DrawRecorder:
+    def __init__(self):
+        self.normals = []
+        self.uniforms = []
+        self._randn = torch.randn
+        self._rand_like = torch.rand_like
+
+    def __enter__(self):
+        def randn(*a, **k):
+            z = self._randn(*a, **k)
+            self.normals.append(z.detach().clone().numpy())
+            return z
+
+        def rand_like(*a, **k):
+            u = self._rand_like(*a, **k)
+            self.uniforms.append(u.detach().clone().numpy())
+            return u
+
+        torch.randn = randn
+        torch.rand_like = rand_like
+        return self
+
+    def __exit__(self, *exc):
+        torch.randn = self._randn
+        torch.rand_like = self._rand_like
+
+    def split(self, n_first_calls_paths, n_second_calls_paths):
+        """Split recorded normals into pre-sim and main-sim blocks by path count."""
+        pre = [z for z in self.normals if z.shape[0] == n_first_calls_paths]
+        return pre
+
+
+def npf(x):
+    if isinstance(x, torch.Tensor):
+        return x.detach().cpu().numpy()
+    return np.asarray(x)
+
+
+def run_controller_case(name, build, n_pre, n_main, num_steps, scheme, differentiate=False, extra=None):
+    """Run one SimulationController case under the recorder and dump everything."""
+    netting_sets, model, risk_metrics = build()
+    captured = {"paths": [], "eval": []}
+
+    orig_gen = MonteCarloEngine.generate_paths
+    orig_eval = SimulationController._evaluate_product
+
+    def gen(self):
+        p = orig_gen(self)
+        captured["paths"].append(npf(p))
+        return p
+
+    def ev(self, product, resolved):
+        r = orig_eval(self, product, resolved)
+        captured["eval"].append({k: npf(v) for k, v in r.items()})
+        return r
+
+    MonteCarloEngine.generate_paths = gen
+    SimulationController._evaluate_product = ev
+    try:
+        sc = SimulationController(
+            netting_sets=netting_sets, model=model, risk_metrics=risk_metrics,
+            num_paths_mainsim=n_main, num_paths_presim=n_pre, num_steps=num_steps,
+            simulation_scheme=scheme, differentiate=differentiate,
+        )
+        with DrawRecorder() as rec:
+            res = sc.run_simulation()
+    finally:
+        MonteCarloEngine.generate_paths = orig_gen
+        SimulationController._evaluate_product = orig_eval
+
+    out = {}
+    out["simulation_timeline"] = npf(sc.simulation_timeline)
+    out["exposure_timeline"] = npf(sc.exposure_timeline)
+    out["metric_exposure_timeline"] = npf(sc.metric_exposure_timeline)
+    n_paths_runs = len(captured["paths"])
+    if n_paths_runs == 2:
+        out["paths_pre"] = captured["paths"][0]
+        out["paths_main"] = captured["paths"][1]
+    else:
+        out["paths_main"] = captured["paths"][0]
+    # draws: split in call order. generate_paths is called pre (if any) then main.
+    normals = rec.normals
+    uniforms = rec.uniforms
+    n_sub = None
+    if n_paths_runs == 2:
+        # each engine consumes the same number of randn calls
+        half = len(normals) // 2
+        out["z_pre"] = np.stack(normals[:half], axis=0)      # [S, N_pre, n_z]
+        out["z_main"] = np.stack(normals[half:], axis=0)     # [S, N_main, n_z]
+        if uniforms:
+            hu = len(uniforms) // 2
+            out["u_pre"] = np.stack(uniforms[:hu], axis=0)
+            out["u_main"] = np.stack(uniforms[hu:], axis=0)
+    else:
+        out["z_main"] = np.stack(normals, axis=0)
+        if uniforms:
+            out["u_main"] = np.stack(uniforms, axis=0)
+    for i, c in enumerate(sc.regression_coeffs):
+        out[f"expo_coeffs_{i}"] = npf(c)
+    for i, p in enumerate(sc.products):
+        if p.regression_coeffs is not None and p.regression_coeffs.numel() > 0:
+            out[f"prod_coeffs_{i}"] = npf(p.regression_coeffs)
+    for i, e in enumerate(captured["eval"]):
+        out[f"cfs_{i}"] = e["discounted_cashflows"]
+        out[f"exposures_{i}"] = e["exposure_profiles"]
+    # metric results [ns][metric][eval] -> (value, err)
+    for ns_i, ns in enumerate(res.results):
+        for m_i, m in enumerate(ns):
+            vals = np.array([[float(v[0]), float(v[1])] for v in m])
+            out[f"result_{ns_i}_{m_i}"] = vals
+    if differentiate:
+        for ns_i, ns in enumerate(res.derivatives):
+            for m_i, m in enumerate(ns):
+                g = np.array([[np.nan if d is None else float(d) for d in ev_] for ev_ in m])
+                out[f"grad_{ns_i}_{m_i}"] = g
+        out["param_names"] = np.array(res.model_param_names)
+    out["metric_names"] = np.array(res.metric_names)
+    out["netting_set_names"] = np.array(res.netting_set_names)
+    if extra:
+        out.update(extra(sc, model))
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: wrote {os.path.getsize(path)/1024:.0f} KiB; results:",
+          {k: v[:2].tolist() for k, v in out.items() if k.startswith("result_")})
+
+
+# ----------------------------------------------------------------------------------------------
+# A. single-step maps and request closed forms
+# ----------------------------------------------------------------------------------------------
+def gen_steps():
+    g = torch.Generator().manual_seed(7)
+    N = 256
+    out = {}
+
+    def rn(*s):
+        return torch.randn(*s, dtype=F64, generator=g)
+
+    def ru(*s):
+        return torch.rand(*s, dtype=F64, generator=g)
+
+    t1 = torch.tensor([0.4], dtype=F64)
+    t2 = torch.tensor([0.65], dtype=F64)
+    dt = t2 - t1
+    out["t1"], out["t2"] = npf(t1), npf(t2)
+
+    # Black-Scholes
+    bs = BlackScholesModel(0.0, 120.0, 0.05, 0.2)
+    S = 120.0 * torch.exp(0.3 * rn(N, 1))
+    z = rn(N, 1)
+    L = bs.get_cholesky(SimulationScheme.ANALYTICAL, dt)
+    out["bs_chol_analytical"] = npf(L)
+    out["bs_state"], out["bs_z"] = npf(S), npf(z)
+    out["bs_exact"] = npf(bs.simulate_time_step_analytically(t1, t2, S, z @ L.T))
+    out["bs_euler"] = npf(bs.simulate_time_step_euler(t1, t2, S, z))
+
+    # Vasicek
+    va = VasicekModel(0.0, 0.03, 0.05, 0.1, 0.01, asset_id="irs")
+    st = torch.stack([0.03 + 0.02 * rn(N), 0.05 * ru(N)], dim=-1)
+    z = rn(N, 1)
+    L = va.get_cholesky(SimulationScheme.ANALYTICAL, dt)
+    out["va_chol_analytical"] = npf(L)
+    out["va_state"], out["va_z"] = npf(st), npf(z)
+    out["va_exact"] = npf(va.simulate_time_step_analytically(t1, t2, st, z @ L.T))
+    out["va_euler"] = npf(va.simulate_time_step_euler(t1, t2, st, z))
+    # closed forms
+    out["va_zcb_0_2"] = npf(va.compute_bond_price(va.calibration_date, torch.tensor(2.0, dtype=F64), st[:, 0]))
+    out["va_zcb_065_3"] = npf(va.compute_bond_price(0.65, 3.0, st[:, 0]))
+    req = AtomicRequest(AtomicRequestType.LIBOR_RATE, 0.4, 0.65)
+    out["va_libor_04_065"] = npf(va.resolve_request(req, "irs", st))
+    req = AtomicRequest(AtomicRequestType.NUMERAIRE, 0.65)
+    out["va_numeraire"] = npf(va.resolve_request(req, "irs", st))
+
+    # CIR++
+    ci = CIRPPModel(0.0, "cp", HAZARDS, kappa=0.1, theta=0.01, volatility=0.02, y0=1e-4)
+    st = torch.stack([torch.abs(0.01 + 0.01 * rn(N)) * (ru(N) > 0.1) - 1e-4 * (ru(N) > 0.9), 0.05 * ru(N)], dim=-1)
+    z = rn(N, 1)
+    out["ci_state"], out["ci_z"] = npf(st), npf(z)
+    out["ci_euler"] = npf(ci.simulate_time_step_euler(t1, t2, st, z))
+    times = np.array([0.0, 0.05, 0.25, 0.4, 0.5, 0.75, 1.0, 1.5, 2.0, 2.5, 3.7, 5.0, 6.2, 9.99, 10.0, 12.5, 19.0, 20.0, 25.0])
+    out["ci_times"] = times
+    out["ci_psi"] = np.array([float(ci.psi(torch.tensor(t, dtype=F64))) for t in times])
+    out["ci_pd"] = np.array([float(ci.cs_helper.probability_of_default(ci.hazard_rates, ci.tenors, torch.tensor(t, dtype=F64)))
+                             for t in times])
+    pairs = [(0.0, 0.25), (0.25, 0.5), (0.4, 0.65), (1.0, 1.25), (2.0, 10.0), (12.25, 12.5), (0.0, 2.0)]
+    out["ci_pairs"] = np.array(pairs)
+    out["ci_cond_survival"] = np.stack([npf(ci.survival_probability(a, b, st[:, 0])) for a, b in pairs], axis=0)
+    req = AtomicRequest(AtomicRequestType.SURVIVAL_PROBABILITY)
+    out["ci_survival"] = npf(ci.resolve_request(req, "cp", st))
+    # deterministic CIR++ (cirpp.py:155-172)
+    cd = CIRPPModel(0.0, "cp", HAZARDS, kappa=0.1, theta=0.01, volatility=0.02, y0=1e-4, deterministic=True)
+    out["cd_euler"] = npf(cd.simulate_time_step_euler(t1, t2, st, z))
+    out["cd_cond_survival"] = np.stack([npf(cd.survival_probability(a, b, st[:, 0])) for a, b in pairs], axis=0)
+    out["cd_init_state"] = npf(cd.get_state(2))
+
+    # Heston
+    he = HestonModel(0.0, 800.0, 0.04, 0.45545583, -0.78975708, 0.01713417, 2.0, 0.0286834)
+    st = torch.stack([np.log(800.0) + 0.2 * rn(N), torch.abs(0.03 + 0.05 * rn(N)) * (ru(N) > 0.15)], dim=-1)
+    z = rn(N, 2)
+    L = he.get_cholesky(SimulationScheme.EULER, None)
+    out["he_chol_euler"] = npf(L)
+    out["he_state"], out["he_z"] = npf(st), npf(z)
+    out["he_euler"] = npf(he.simulate_time_step_euler(t1, t2, st, z @ L.T))
+    for smooth, tag in ((False, "hard"), (True, "fuzzy")):
+        he.perform_smoothing = smooth
+        with DrawRecorder() as rec:
+            torch.manual_seed(11)
+            res = he.simulate_time_step_qe(t1, t2, st, z)
+        out[f"he_qe_{tag}"] = npf(res)
+        out[f"he_qe_{tag}_u"] = rec.uniforms[0]
+    # a high-psi regime (small mean variance, high vol-of-vol): exercises the exponential branch
+    he2 = HestonModel(0.0, 100.0, 0.02, 1.2, -0.5, 0.5, 0.02, 0.02)
+    st2 = torch.stack([np.log(100.0) + 0.2 * rn(N), torch.abs(0.01 * rn(N)) * (ru(N) > 0.3)], dim=-1)
+    out["he2_state"] = npf(st2)
+    for smooth, tag in ((False, "hard"), (True, "fuzzy")):
+        he2.perform_smoothing = smooth
+        with DrawRecorder() as rec:
+            torch.manual_seed(12)
+            res = he2.simulate_time_step_qe(t1, t2, st2, z)
+        out[f"he2_qe_{tag}"] = npf(res)
+        out[f"he2_qe_{tag}_u"] = rec.uniforms[0]
+
+    # ModelConfig Cholesky factors (model_config.py:101-142, model.py:50-73)
+    for rho in (-0.95, 0.0, 0.5, 0.99999):
+        mc = ModelConfig([VasicekModel(0.0, 0.03, 0.05, 0.1, 0.01, asset_id="irs"),
+                          CIRPPModel(0.0, "cp", HAZARDS, 0.1, 0.01, 0.02, 1e-4)],
+                         inter_asset_correlation_matrix=np.array([rho]))
+        out[f"mc_chol_{rho}"] = npf(mc.get_cholesky(SimulationScheme.EULER, None))
+    models = [BlackScholesModel(0.0, 100.0, 0.0, 0.4, asset_id=f"a{i}") for i in range(4)]
+    mc = ModelConfig(models, inter_asset_correlation_matrix=np.array([[0.5]] * 6))
+    out["mc4_chol_euler"] = npf(mc.get_cholesky(SimulationScheme.EULER, None))
+    out["mc4_chol_analytical"] = npf(mc.get_cholesky(SimulationScheme.ANALYTICAL, torch.tensor([0.25], dtype=F64)))
+
+    path = os.path.join(OUT, "steps.npz")
+    np.savez_compressed(path, **out)
+    print("steps:", os.path.getsize(path) // 1024, "KiB")
+
+
+# ----------------------------------------------------------------------------------------------
+# B. engine-only path generation (ModelConfig of 4 correlated BS, exact + Euler)
+# ----------------------------------------------------------------------------------------------
+def gen_paths_mc4():
+    out = {}
+    for scheme, tag, steps in ((SimulationScheme.ANALYTICAL, "exact", 2), (SimulationScheme.EULER, "euler", 5)):
+        models = [BlackScholesModel(0.0, 100.0 + 5 * i, 0.01 * i, 0.2 + 0.1 * i, asset_id=f"a{i}") for i in range(4)]
+        mc = ModelConfig(models, inter_asset_correlation_matrix=np.array([[0.5], [0.3], [-0.2], [0.1], [0.4], [0.6]]))
+        tl = torch.tensor([0.0, 0.5, 1.0, 1.75], dtype=F64)
+        eng = MonteCarloEngine(tl, scheme, mc, 512, steps, False)
+        with DrawRecorder() as rec:
+            p = eng.generate_paths()
+        out[f"{tag}_paths"] = npf(p)
+        out[f"{tag}_z"] = np.stack(rec.normals, axis=0)
+        out[f"{tag}_timeline"] = npf(tl)
+    path = os.path.join(OUT, "paths_mc4.npz")
+    np.savez_compressed(path, **out)
+    print("paths_mc4:", os.path.getsize(path) // 1024, "KiB")
+
+
+# ----------------------------------------------------------------------------------------------
+# C. controller cases (shrunk BASELINE configs)
+# ----------------------------------------------------------------------------------------------
+def case_bs_european():
+    model = BlackScholesModel(0, 120.0, 0.05, 0.2)
+    prod = EuropeanOption(Equity(), 2.0, 100.0, OptionType.CALL)
+    pv = PVMetric()
+    return [NettingSet(name=prod.get_name(), products=[prod])], model, RiskMetrics([pv])
+
+
+def case_bs_put_euler():
+    model = BlackScholesModel(0, 90.0, 0.03, 0.35)
+    prod = EuropeanOption(Equity(), 1.5, 100.0, OptionType.PUT)
+    pv = PVMetric()
+    return [NettingSet(name=prod.get_name(), products=[prod])], model, RiskMetrics([pv])
+
+
+def _irs_models(rho, a=0.1, sig=0.01):
+    ir = VasicekModel(0.0, 0.03, 0.05, a, sig, asset_id="irs")
+    cr = CIRPPModel(0.0, "cp", HAZARDS, kappa=0.1, theta=0.01, volatility=0.02, y0=1e-4)
+    return ModelConfig([ir, cr], inter_asset_correlation_matrix=np.array([rho]))
+
+
+def case_irs_cva():
+    model = _irs_models(0.5)
+    irs = InterestRateSwap(0.0, 2.5, 1.0, 0.03, 0.25, 0.25, IRSType.PAYER, "irs")
+    ns = [NettingSet(name=irs.get_name(), products=[irs], counterparty_id="cp")]
+    tl = np.arange(11) * 0.25
+    return ns, model, RiskMetrics([CVAMetric("cp", 0.4)], exposure_timeline=tl)
+
+
+def case_irs_cva_linspace():
+    """reference test parameters (tests/pytests/test_cva.py:122-172) on a shrunk horizon; linspace dates interleave payments"""
+    model = _irs_models(0.99999, a=0.02, sig=0.2)
+    irs = InterestRateSwap(0.0, 2.0, 1.0, 0.03, 0.25, 0.25, IRSType.PAYER, "irs")
+    ns = [NettingSet(name=irs.get_name(), products=[irs], counterparty_id="cp")]
+    tl = np.linspace(0, 2.0, 7)
+    return ns, model, RiskMetrics([CVAMetric("cp", 0.4), PVMetric(), EPEMetric(), ENEMetric()], exposure_timeline=tl)
+
+
+def case_zcb_cva():
+    ir = VasicekModel(0.0, 0.03, 0.05, 1.0, 0.2, asset_id="bond")
+    cr = CIRPPModel(0.0, "cp", HAZARDS, kappa=0.1, theta=0.01, volatility=0.02, y0=1e-4)
+    model = ModelConfig([ir, cr], inter_asset_correlation_matrix=np.array([0.0]))
+    zb = Bond(0.0, 2.0, 1, 2.0, True, 0.0, "bond")
+    ns = [NettingSet(name=zb.get_name(), products=[zb], counterparty_id="cp")]
+    tl = np.linspace(0, 2.0, 9)
+    return ns, model, RiskMetrics([CVAMetric("cp", 0.4)], exposure_timeline=tl)
+
+
+def case_heston():
+    model = HestonModel(0, 800.0, 0.04, 0.45545583, -0.78975708, 0.01713417, 2.0, 0.0286834)
+    prod = EuropeanOption(Equity(), 1.0, 720.0, OptionType.CALL)
+    return [NettingSet(name=prod.get_name(), products=[prod])], model, RiskMetrics([PVMetric()])
+
+
+def case_heston_highpsi():
+    model = HestonModel(0, 100.0, 0.02, 1.2, -0.5, 0.5, 0.02, 0.02)
+    prod = EuropeanOption(Equity(), 1.0, 95.0, OptionType.PUT)
+    return [NettingSet(name=prod.get_name(), products=[prod])], model, RiskMetrics([PVMetric()])
+
+
+def case_bermudan_swaption():
+    model = VasicekModel(0.0, 0.03, 0.05, 0.1, 0.01)
+    und = InterestRateSwap(0.0, 2.0, 1.0, 0.03, 0.25, 0.25, IRSType.PAYER)
+    ex = [0.125 * k for k in range(1, 16)]
+    prod = BermudanOption(und, ex, 0.0, OptionType.CALL)
+    ns = [NettingSet(name="berm_ns", products=[prod])]
+    tl = np.array([0.125 * k for k in range(0, 17)])
+    mets = [EPEMetric(), PFEMetric(0.95), ENEMetric(), EEPEMetric(), CEMetric(), PVMetric(), PFEMetric(0.5)]
+    return ns, model, RiskMetrics(mets, exposure_timeline=tl)
+
+
+def case_american():
+    model = BlackScholesModel(0.0, 100.0, 0.05, 0.5)
+    prod = AmericanOption(Equity("id"), 3.0, 12, 100.0, OptionType.PUT)
+    return [NettingSet(name=prod.get_name(), products=[prod])], model, RiskMetrics([PVMetric()])
+
+
+def case_netting():
+    """two netting sets on one Vasicek model: threshold + MPoR collateral (netting_set.py:48-184)"""
+    model = VasicekModel(0.0, 0.02, 0.04, 0.3, 0.015, asset_id="r")
+    irs1 = InterestRateSwap(0.0, 2.0, 1.0, 0.025, 0.5, 0.25, IRSType.PAYER, "r")
+    irs2 = InterestRateSwap(0.0, 1.5, 2.0, 0.035, 0.5, 0.5, IRSType.RECEIVER, "r")
+    bond = Bond(0.0, 2.0, 0.1, 0.5, True, 0.03, "r")
+    frn = Bond(0.0, 1.0, 0.05, 0.25, True, None, "r")
+    ns1 = NettingSet(name="ns_coll", products=[irs1, bond], threshold=0.002, margin_period_of_risk=0.25)
+    ns2 = NettingSet(name="ns_thr", products=[irs2, frn], threshold=0.01)
+    tl = np.array([0.0, 0.25, 0.5, 0.75, 1.0, 1.5, 2.0])
+    mets = [EPEMetric(), ENEMetric(), PFEMetric(0.9), PVMetric(), EEPEMetric(), CEMetric()]
+    return [ns1, ns2], model, RiskMetrics(mets, exposure_timeline=tl)
+
+
+def case_bond_option():
+    """European option on a coupon bond and on a swap under Vasicek (european_option.py:45-68, bond.py:115-163)"""
+    model = VasicekModel(0.0, 0.03, 0.05, 0.2, 0.02, asset_id="r")
+    und_b = Bond(0.0, 3.0, 1.0, 0.5, True, 0.04, "r")
+    und_s = InterestRateSwap(0.0, 3.0, 1.0, 0.035, 0.5, 0.25, IRSType.PAYER, "r")
+    o1 = EuropeanOption(und_b, 1.0, 0.98, OptionType.CALL, asset_id="r")
+    o1.name = "bond_call"
+    o2 = EuropeanOption(und_s, 1.0, 0.0, OptionType.PUT, asset_id="r")
+    o2.name = "swaption_put"
+    ns = [NettingSet(name="o1", products=[o1]), NettingSet(name="o2", products=[o2])]
+    return ns, model, RiskMetrics([PVMetric()])
+
+
+def case_mixed_cva():
+    """BS + Vasicek + deterministic CIR++ book (tests/exposure_tests/cva_large_netting_set_derivatives.py:133-171), tiny"""
+    eq = BlackScholesModel(0.0, 100.0, 0.03, 0.22, asset_id="equity")
+    ra = VasicekModel(0.0, 0.03, 0.03, 1.0, 0.01, asset_id="rates")
+    cr = CIRPPModel(0.0, "cp", HAZARDS, kappa=0.10, theta=0.01, volatility=0.02, y0=1e-4, deterministic=True)
+    model = ModelConfig([eq, ra, cr], inter_asset_correlation_matrix=[np.array([0.0])] * 3)
+    prods = []
+    o = EuropeanOption(Equity("equity"), 1.0, 95.0, OptionType.CALL, asset_id="equity"); o.name = "call0"; prods.append(o)
+    o = EuropeanOption(Equity("equity"), 2.0, 105.0, OptionType.CALL, asset_id="equity"); o.name = "call1"; prods.append(o)
+    b = Bond(0.0, 2.0, 2.0, 0.5, True, 0.02, "rates"); b.name = "bond0"; prods.append(b)
+    s = InterestRateSwap(0.0, 2.0, 25.0, 0.025, 0.5, 0.25, IRSType.PAYER, "rates"); s.name = "swap0"; prods.append(s)
+    ns = [NettingSet(name="mixed", products=prods, counterparty_id="cp")]
+    tl = np.linspace(0.0, 2.5, 8)
+    return ns, model, RiskMetrics([CVAMetric("cp", 0.4), EPEMetric()], exposure_timeline=tl)
+
+
+def main():
+    torch.set_num_threads(4)
+    gen_steps()
+    gen_paths_mc4()
+    A, E, Q = SimulationScheme.ANALYTICAL, SimulationScheme.EULER, SimulationScheme.QE
+    run_controller_case("bs_european", case_bs_european, 0, 2048, 10, A)
+    run_controller_case("bs_european_aad", case_bs_european, 0, 2048, 10, A, differentiate=True)
+    run_controller_case("bs_put_euler_aad", case_bs_put_euler, 0, 1024, 8, E, differentiate=True)
+    run_controller_case("irs_cva", case_irs_cva, 1024, 1024, 2, E)
+    run_controller_case("irs_cva_linspace", case_irs_cva_linspace, 1024, 1024, 2, E)
+    run_controller_case("zcb_cva", case_zcb_cva, 1024, 1024, 2, E)
+    run_controller_case("heston_qe", case_heston, 0, 1024, 8, Q)
+    run_controller_case("heston_qe_aad", case_heston, 0, 1024, 8, Q, differentiate=True)
+    run_controller_case("heston_highpsi_qe", case_heston_highpsi, 0, 1024, 6, Q)
+    run_controller_case("heston_euler", case_heston, 0, 1024, 8, E)
+    run_controller_case("bermudan_swaption", case_bermudan_swaption, 1024, 1024, 1, E)
+    run_controller_case("american_put", case_american, 2048, 1024, 1, A)
+    run_controller_case("netting", case_netting, 1024, 1024, 1, A)
+    run_controller_case("bond_option", case_bond_option, 0, 1024, 2, A)
+    run_controller_case("mixed_cva", case_mixed_cva, 512, 512, 2, E)
+
+
+if __name__ == "__main__":
+    main()
