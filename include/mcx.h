@@ -1,0 +1,277 @@
+/*
+ * mcx.h — C ABI of the MI355X-native Monte-Carlo path & exposure engine (libmcx_hip.so).
+ *
+ * The reference (konstantineder/montecarlo-risk-engine) is pure Python on torch-CPU and has NO FFI; its seams are
+ * Python call signatures.  This header is the boundary a maintainer would bind (ctypes) to replace, for ONE hot path:
+ *
+ *   reference seam (file:line)                                   entry point here
+ *   ------------------------------------------------------------ -------------------------------------------
+ *   MonteCarloEngine.generate_paths        engine/engine.py:27-123        mcx_generate_paths          (K1)
+ *   Model.generate_correlated_randn        models/model.py:38-48          (inside K1: Philox4x32-10 + Box-Muller + L·z)
+ *   *.simulate_time_step_{analytically,euler,qe}  models/<model>.py           (inside K1)
+ *   RequestInterface.resolve_requests      request_interface.py:115-130   mcx_resolve_atoms / fused in K2
+ *   SimulationController._evaluate_product controller/controller.py:385-471   mcx_eval_book           (K2)
+ *   SimulationController._perform_regression_for_product  controller.py:294-383  mcx_lsm_stats, mcx_lsm_step (K3)
+ *   NettingSet.compute_unsecured_exposure_profiles  products/netting_set.py:156-184   (prologue of K4/K5)
+ *   Metric._compute_mc_mean_and_error + PV/CE/EPE/ENE/CVA  metrics/<metric>.py   mcx_reduce_vector, mcx_reduce_profiles, mcx_reduce_cva (K4)
+ *   PFEMetric.evaluate_numerically (torch.sort)     metrics/pfe_metric.py:49-73       mcx_select_hist  (K5)
+ *
+ * Conventions
+ *   - every d_* pointer is DEVICE memory owned by the caller (torch.empty(device="cuda").data_ptr()); the library never
+ *     frees caller memory and keeps no reference to it after the call returns.
+ *   - every h_* / descriptor pointer is HOST memory, copied during the call.
+ *   - all floating point is IEEE binary64.  Layout of paths: [T][D][ld] with the path index contiguous (ld >= n_paths).
+ *   - calls enqueue on the hipStream_t passed as `stream` (NULL = default stream) and return without synchronising,
+ *     except where an h_* output is written (then the call synchronises that stream).
+ *   - return 0 on success, <0 on error; mcx_last_error() describes the last failure on that handle.
+ *   - one handle per GPU; a handle is not thread-safe; distinct handles may be used from distinct threads.
+ *
+ * The same descriptors are consumed by the CPU oracle (oracle/mcx_oracle.c, prefix orc_) which is TEST infrastructure.
+ */
+#ifndef MCX_H
+#define MCX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCX_ABI_VERSION 1
+
+#define MCX_MAX_SLOTS   8    /* sub-models in one ModelConfig                                  */
+#define MCX_MAX_Z       8    /* total simulation dimension (correlated normals per sub-step)    */
+#define MCX_MAX_STATE   16   /* total state dimension D                                         */
+#define MCX_SLOT_NPARAM 8
+#define MCX_AUX         8    /* host-precomputed per-(sub-step, slot) constants                 */
+#define MCX_MAX_BASIS   6    /* regression basis functions (polynomial degree + 1)              */
+#define MCX_MAX_STATES  4    /* product exercise states (Bermudan: 2)                           */
+
+/* SimulationScheme values mirror common/enums.py:4-9 */
+enum { MCX_SCHEME_EULER = 0, MCX_SCHEME_MILSTEIN = 1, MCX_SCHEME_ANALYTICAL = 2, MCX_SCHEME_QE = 3 };
+
+/* sub-model kinds */
+enum {
+    MCX_MODEL_BS        = 1, /* p = [spot, sigma, rate]                       state [S]        black_scholes.py:50-85      */
+    MCX_MODEL_HESTON    = 2, /* p = [spot, sigma_v, rate, rho, kappa, theta, v0]  state [logS, v]  heston.py:99-253        */
+    MCX_MODEL_VASICEK   = 3, /* p = [r0, sigma, theta, a]                     state [r, logB]  vasicek.py:61-112           */
+    MCX_MODEL_CIRPP     = 4, /* p = [kappa, theta, sigma, y0]                 state [y, Lambda] cirpp.py:174-198           */
+    MCX_MODEL_CIRPP_DET = 5, /* deterministic hazard                          state [lam, Lambda] cirpp.py:155-172         */
+    MCX_MODEL_HW        = 6  /* Hull-White 1F: p = [r0, sigma, -, a], theta(t) in aux   hull_white.py:58-88 (spec only)    */
+};
+
+/* per-(sub-step, slot) aux[] semantics (filled by the host from the model parameters and dt):
+ *   BS        ANALYTICAL: aux0 = rate*dt, aux1 = 0.5*dt*sigma^2          EULER: unused
+ *   VASICEK   ANALYTICAL: aux0 = exp(-a*dt)                               EULER: unused
+ *   HW        ANALYTICAL: aux0 = exp(-a*dt), aux1 = mean shift alpha(t2)-alpha(t1)*exp(-a dt); EULER: aux0 = theta(t1)
+ *   CIRPP     EULER:      aux0 = psi(t1)
+ *   CIRPP_DET any:        aux0 = lambda_mkt(t1), aux1 = lambda_mkt(t2)
+ *   HESTON    QE:         aux0 = E = exp(-kappa dt), aux1..aux5 = K0..K4, aux6 = sigma^2 E (1-E)/kappa, aux7 = theta sigma^2 (1-E)^2/(2 kappa)
+ */
+
+#define MCX_FLAG_SMOOTHING 1  /* Model.perform_smoothing (fuzzy QE branches), model.py:83-90 */
+
+typedef struct {
+    int32_t kind;
+    int32_t state_off;   /* first state column of this sub-model        */
+    int32_t z_off;       /* first correlated normal consumed            */
+    int32_t flags;
+    double  p[MCX_SLOT_NPARAM];
+} mcx_slot;
+
+typedef struct {
+    double  dt;          /* sub-step length (engine.py:49-50)                                        */
+    double  sqrt_dt;
+    double  t1;          /* start time of the sub-step: accumulated t_prev (engine.py:60)            */
+    int32_t store_idx;   /* timeline index stored after this sub-step, -1 = none                      */
+    int32_t chol_idx;    /* Cholesky factor used (one per distinct dt for ANALYTICAL, model.py:56-64) */
+} mcx_step;
+
+typedef struct {
+    int32_t scheme;           /* MCX_SCHEME_*                                                         */
+    int32_t n_slots;
+    int32_t n_state;          /* D                                                                    */
+    int32_t n_z;              /* normals per sub-step                                                 */
+    int32_t n_uniform;        /* extra uniforms per sub-step (Heston QE: 1, heston.py:192)            */
+    int32_t n_steps;          /* total sub-steps S                                                    */
+    int32_t n_dates;          /* stored timeline dates T                                              */
+    int32_t n_chol;
+    int32_t n_initial_store;  /* leading timeline dates stored before any step (t == calibration date)*/
+    int32_t flags;
+    mcx_slot slots[MCX_MAX_SLOTS];
+    const mcx_step* steps;    /* [n_steps]                                                            */
+    const double*   chol;     /* [n_chol][n_z][n_z] row-major, lower triangular                       */
+    const double*   aux;      /* [n_steps][n_slots][MCX_AUX]                                          */
+    const double*   init_state; /* [n_state]                                                          */
+} mcx_sim_desc;
+
+/* ---- RNG contract (bit-exact between oracle and HIP) ----------------------------------------------------------------
+ * Philox4x32-10 (Salmon et al. 2011, Random123 constants M0=0xD2511F53 M1=0xCD9E8D57 W0=0x9E3779B9 W1=0xBB67AE85).
+ *   key     = (seed_lo, seed_hi)
+ *   counter = (path_lo, path_hi, sub_step, draw)        path = path_offset + local path index
+ *   out (w0,w1,w2,w3):  ua = ((w0 | w1<<32) >> 11 + 0.5) * 2^-53 ,  ub likewise from (w2,w3)   (both in (0,1))
+ *   Box-Muller: r = sqrt(-2 ln ua); z[2*draw] = r cos(2 pi ub); z[2*draw+1] = r sin(2 pi ub)
+ *   extra uniform j (Heston QE) = ua of draw index ceil(n_z/2)+j
+ * Inject mode (parity against recorded reference draws): d_inject_z [n_steps][n_z][ld], d_inject_u [n_steps][ld].
+ */
+
+/* ---- book program (K2) ------------------------------------------------------------------------------------------- */
+
+/* atom: a per-path market quantity at one timeline date (the reference's AtomicRequest resolved by a model):
+ *   value = a + d*x + b*exp(c0 + c1*x),   x = paths[t_idx][col][n]   (col < 0: x = 0)
+ * covers SPOT, NUMERAIRE, DISCOUNT_FACTOR, FORWARD_RATE (ZCB), LIBOR_RATE, SURVIVAL and CONDITIONAL_SURVIVAL for every
+ * supported model (vasicek.py:114-156, cirpp.py:246-317, black_scholes.py:87-111, heston.py:255-280). */
+typedef struct {
+    int32_t t_idx;
+    int32_t col;
+    double  a, d, b, c0, c1;
+} mcx_atom;
+
+typedef struct {
+    double  w;
+    int32_t atom;
+    int32_t den;    /* -1: divided by the event's numeraire; >= 0: this term is divided by atom `den` instead.  Needed for a
+                       reference quirk: a swap leg's payment-index labels are looked up in the swap's MERGED timeline
+                       (request_interface.py:61-66 with swap.py:86-100), so with tenor_fixed != tenor_float a leg's
+                       numeraire / LIBOR are read from the state at another date than the payment date. */
+} mcx_term;
+
+enum {
+    MCX_EV_CASHFLOW    = 1, /* cfs += sum_j w_j atom_j / (den_j or numeraire)                      bond.py:171-214, swap.py:142-172              */
+    MCX_EV_OPTION      = 2, /* cfs += max(sign*(value-strike),0)/numeraire  european_option.py:45-68                      */
+    MCX_EV_EXERCISE    = 3, /* Bermudan exercise step                       bermudan_option.py:93-131                     */
+    MCX_EV_EXPO_POLY   = 4, /* expo[row] += poly(x; coeffs[state])/numeraire  controller.py:439-447, product.py:157-184   */
+    MCX_EV_EXPO_BS     = 5  /* analytic Black-Scholes exposure              european_option.py:123-145                    */
+};
+
+typedef struct {
+    int32_t kind;
+    int32_t t_idx;
+    int32_t num_atom;      /* numeraire atom                                                                     */
+    int32_t x_atom;        /* explanatory atom (EXERCISE / EXPO_*), -1 = none                                    */
+    int32_t term_begin;    /* value = sum_{j in [term_begin, term_end)} terms[j].w * atom(terms[j].atom)          */
+    int32_t term_end;
+    int32_t coeff_off;     /* offset in coeffs[] of this date's [n_states][n_basis] block; -1 = continuation 0   */
+    int32_t expo_row;      /* row of the exposure matrix (EXPO_*)                                                */
+    double  strike;
+    double  sign;          /* +1 call / -1 put                                                                   */
+    double  aux[4];        /* EXPO_BS: sigma, rate, remaining maturity                                           */
+} mcx_event;
+
+typedef struct {
+    int32_t ev_begin, ev_end;   /* main-simulation stream: cashflow + exposure events in evaluation order (controller.py:414-461) */
+    int32_t cf_begin, cf_end;   /* product-date events only, product-timeline order (LSM roll, controller.py:333-341)              */
+    int32_t netting_set;
+    int32_t init_state;         /* product.get_initial_state()                                                                     */
+    int32_t n_states;           /* product.get_num_states()                                                                        */
+    int32_t flags;
+} mcx_product;
+
+typedef struct {
+    int32_t n_atoms, n_terms, n_events, n_products;
+    int32_t n_netting_sets, n_expo_rows, n_basis, n_coeffs;
+    int32_t want_cfs, want_expo;
+    const mcx_atom*    atoms;
+    const mcx_term*    terms;
+    const mcx_event*   events;
+    const mcx_product* products;
+    const double*      coeffs;     /* [n_coeffs] initial regression coefficients (usually zeros) */
+} mcx_book_desc;
+
+/* ---- metrics (K4/K5) ---------------------------------------------------------------------------------------------- */
+
+/* unsecured exposure of one netting set at metric date m (netting_set.py:156-184):
+ *   not collateralised: thr(E[row[m]])            collateralised: E[row[m]] - (delayed[m] >= 0 ? thr(E[delayed[m]]) : 0)
+ *   thr(x) = x > h ? x-h : (x < -h ? x+h : 0)  (h == 0: identity)                                netting_set.py:48-72 */
+typedef struct {
+    int32_t n_dates;            /* metric exposure dates                                     */
+    int32_t collateralized;
+    double  threshold;
+    const int32_t* row;         /* [n_dates] row of the netting set's exposure block          */
+    const int32_t* delayed;     /* [n_dates] delayed row or -1 (NULL if not collateralised)   */
+} mcx_unsecured_desc;
+
+/* accumulator record written by every reduction: sums of (x - shift) over the local paths */
+typedef struct {
+    double n;       /* number of paths reduced      */
+    double shift;   /* x of the first local path    */
+    double s1;      /* sum (x - shift)              */
+    double s2;      /* sum (x - shift)^2            */
+} mcx_acc;
+
+typedef struct mcx_handle mcx_handle;
+typedef struct mcx_sim    mcx_sim;
+typedef struct mcx_book   mcx_book;
+
+int         mcx_abi_version(void);
+int         mcx_create(mcx_handle** out, int device_id);
+void        mcx_destroy(mcx_handle* h);
+const char* mcx_last_error(mcx_handle* h);
+int         mcx_device_info(mcx_handle* h, int32_t* n_cu, int64_t* hbm_bytes, char* name, int32_t name_len);
+
+/* K1 — replaces MonteCarloEngine(...).generate_paths() (engine/engine.py:10-33). */
+int  mcx_sim_create(mcx_handle* h, const mcx_sim_desc* desc, mcx_sim** out);
+void mcx_sim_destroy(mcx_sim* sim);
+int  mcx_generate_paths(mcx_handle* h, const mcx_sim* sim, uint64_t seed, uint64_t path_offset, int64_t n_paths,
+                        int64_t ld, double* d_paths /* [n_dates][n_state][ld] */,
+                        const double* d_inject_z, const double* d_inject_u, void* stream);
+
+/* K2 — replaces RequestInterface.resolve_requests + SimulationController._evaluate_product summed per netting set
+ * (controller/controller.py:385-471, 584-591). d_cfs [n_netting_sets][ld_out], d_expo [n_netting_sets][n_expo_rows][ld_out]. */
+int  mcx_book_create(mcx_handle* h, const mcx_book_desc* desc, mcx_book** out);
+void mcx_book_destroy(mcx_book* book);
+int  mcx_book_set_coeffs(mcx_handle* h, mcx_book* book, int64_t offset, int64_t count, const double* h_coeffs, void* stream);
+int  mcx_eval_book(mcx_handle* h, const mcx_book* book, const double* d_paths, int64_t n_paths, int64_t ld,
+                   double* d_cfs, double* d_expo, int64_t ld_out, void* stream);
+/* materialise resolved requests for pluggable Metric subclasses (request_interface.py:115-130): d_out [n_ids][ld_out] */
+int  mcx_resolve_atoms(mcx_handle* h, const mcx_book* book, const int32_t* h_atom_ids, int32_t n_ids,
+                       const double* d_paths, int64_t n_paths, int64_t ld, double* d_out, int64_t ld_out, void* stream);
+
+/* K3 — Longstaff-Schwartz normal equations (controller/controller.py:316-374).
+ * mcx_lsm_stats: h_out[2*i+0] = min x_i, h_out[2*i+1] = max x_i over local paths for each explanatory atom (basis centring /
+ *                scaling z = (x-shift)*scale, and detection of the exactly rank-1 regression at the calibration date).
+ * mcx_lsm_step : for every path and hypothetical start state s0, accumulate the cashflows of product-date events
+ *                roll_begin .. roll_end-1 forward along the exercise policy and add the cached tail W[final state]
+ *                (d_W [n_states][ld_w] in/out, the reference's cf_cache), then with z = (x - shift)*scale and
+ *                Y_s = numeraire * W[s] accumulate   d_moments[k] = sum z^k (k < 2K-1),  d_moments[2K-1 + s*K + k] = sum z^k Y_s.
+ *                d_moments is device memory (so it can be all-reduced over RCCL before the host solve).
+ *                flags: MCX_LSM_MFMA selects the v_mfma_f64_16x16x4_f64 Gram kernel (default: VALU + wave reduction);
+ *                MCX_LSM_F32_CACHE reproduces the reference's float32 cf_cache (torch.zeros without dtype,
+ *                controller.py:312-317,330): the running cashflow sum is rounded to float32 after every product date. */
+#define MCX_LSM_MFMA      1
+#define MCX_LSM_F32_CACHE 2
+int  mcx_lsm_stats(mcx_handle* h, const mcx_book* book, const int32_t* h_atom_ids, int32_t n_ids,
+                   const double* d_paths, int64_t n_paths, int64_t ld, double* h_out, void* stream);
+int  mcx_lsm_step(mcx_handle* h, const mcx_book* book, int32_t product, int32_t roll_begin, int32_t roll_end,
+                  int32_t num_atom, int32_t x_atom, double shift, double scale,
+                  const double* d_paths, int64_t n_paths, int64_t ld,
+                  double* d_W, int64_t ld_w, double* d_moments, int32_t flags, void* stream);
+
+/* K4 — reductions. Every output record is an mcx_acc (host memory, valid on return).
+ * mcx_reduce_vector  : PVMetric on cfs (pv_metric.py:17-18)                                   h_out[1]
+ * mcx_reduce_profiles: EPE / ENE per metric date (epe_metric.py:11-16, ene_metric.py:11-16)   h_out[2*n_dates] = {pos_m, neg_m}
+ * mcx_reduce_cva     : sum_{m<n_dates-1} relu(u_m) * S(0,t_m) * (1 - S(t_m,t_{m+1})) * (1-R)   (cva_metric.py:62-100)  h_out[1]
+ *                      surv_atoms / cond_atoms: [n_dates-1] atom ids in `book`. */
+int  mcx_reduce_vector(mcx_handle* h, const double* d_x, int64_t n_paths, mcx_acc* h_out, void* stream);
+int  mcx_reduce_profiles(mcx_handle* h, const mcx_unsecured_desc* u, const double* d_expo_ns, int64_t n_paths, int64_t ld,
+                         mcx_acc* h_out, void* stream);
+int  mcx_reduce_cva(mcx_handle* h, const mcx_book* book, const mcx_unsecured_desc* u,
+                    const int32_t* h_surv_atoms, const int32_t* h_cond_atoms, double recovery,
+                    const double* d_expo_ns, const double* d_paths, int64_t n_paths, int64_t ld_expo, int64_t ld_paths,
+                    mcx_acc* h_out, void* stream);
+/* materialise unsecured exposures for pluggable metrics: d_out [n_dates][ld_out] */
+int  mcx_unsecured(mcx_handle* h, const mcx_unsecured_desc* u, const double* d_expo_ns, int64_t n_paths, int64_t ld,
+                   double* d_out, int64_t ld_out, void* stream);
+
+/* K5 — one radix-select pass for exact order statistics (pfe_metric.py:49-73 without sorting).
+ * key(x) = order-preserving uint64 image of the double. For each metric date m and each of n_sel selections j the pass
+ * histograms the `bits`-wide digit at `shift` of every unsecured exposure whose key matches prefix[m*n_sel+j] on the bits
+ * above (shift+bits).  d_hist [n_dates][n_sel][1<<bits] uint64 counters (device, zeroed by the call, all-reducible). */
+int  mcx_select_hist(mcx_handle* h, const mcx_unsecured_desc* u, const double* d_expo_ns, int64_t n_paths, int64_t ld,
+                     int32_t n_sel, const uint64_t* h_prefix, int32_t shift, int32_t bits,
+                     uint64_t* d_hist, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCX_H */

@@ -1,0 +1,255 @@
+"""ctypes binding of libmcx_hip.so — the ONLY compute backend of the product.
+
+There is no CPU fallback: if the HIP library is missing, or no GPU is visible, construction fails loudly.
+PyTorch-ROCm is used as the container of device memory (torch.empty(device="cuda")) and for the current HIP stream;
+every numeric kernel on the hot path is hand-written HIP behind the C ABI of include/mcx.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from . import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libmcx_hip.so")
+
+_EXPORTS = [
+    "mcx_abi_version", "mcx_create", "mcx_destroy", "mcx_last_error", "mcx_device_info",
+    "mcx_sim_create", "mcx_sim_destroy", "mcx_generate_paths",
+    "mcx_book_create", "mcx_book_destroy", "mcx_book_set_coeffs", "mcx_eval_book", "mcx_resolve_atoms",
+    "mcx_lsm_stats", "mcx_lsm_step",
+    "mcx_reduce_vector", "mcx_reduce_profiles", "mcx_reduce_cva", "mcx_unsecured", "mcx_select_hist",
+]
+
+
+def load_library(path: str = LIB_PATH) -> C.CDLL:
+    if not os.path.exists(path):
+        raise RuntimeError(f"HIP extension not built: {path} is missing. Run `python -c 'import __graft_entry__ as g; "
+                           f"g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(path)
+    for name in _EXPORTS:
+        if not hasattr(lib, name):
+            raise RuntimeError(f"{path} does not export {name}")
+    lib.mcx_last_error.restype = C.c_char_p
+    lib.mcx_last_error.argtypes = [C.c_void_p]
+    lib.mcx_destroy.restype = None
+    lib.mcx_sim_destroy.restype = None
+    lib.mcx_book_destroy.restype = None
+    if lib.mcx_abi_version() != _abi.ABI_VERSION:
+        raise RuntimeError("libmcx_hip.so ABI version mismatch")
+    return lib
+
+
+def _vp(x) -> C.c_void_p:
+    return C.c_void_p(int(x))
+
+
+class HipBackend:
+    """One per process / GPU. Methods mirror the C ABI one-to-one; tensors are torch CUDA tensors (float64)."""
+
+    name = "hip"
+
+    def __init__(self, device_index: int | None = None):
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise RuntimeError("no AMD GPU visible (torch.cuda.is_available() is False); the MI355X path has no CPU fallback")
+        if device_index is None:
+            device_index = torch.cuda.current_device()
+        self.device = torch.device("cuda", device_index)
+        torch.cuda.set_device(self.device)
+        h = C.c_void_p()
+        rc = self.lib.mcx_create(C.byref(h), C.c_int(device_index))
+        if rc != 0:
+            raise RuntimeError(f"mcx_create failed ({rc})")
+        self.h = h
+        self._keep = []
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.mcx_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ---- helpers -------------------------------------------------------------------------------------------------
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            msg = self.lib.mcx_last_error(self.h)
+            raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    def _stream(self) -> C.c_void_p:
+        return _vp(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def empty(self, *shape, dtype=torch.float64) -> torch.Tensor:
+        return torch.empty(*shape, dtype=dtype, device=self.device)
+
+    def zeros(self, *shape, dtype=torch.float64) -> torch.Tensor:
+        return torch.zeros(*shape, dtype=dtype, device=self.device)
+
+    def from_numpy(self, a: np.ndarray) -> torch.Tensor:
+        return torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+
+    def synchronize(self):
+        torch.cuda.synchronize(self.device)
+
+    def device_info(self) -> dict:
+        ncu, hbm = C.c_int32(), C.c_int64()
+        name = C.create_string_buffer(256)
+        self._check(self.lib.mcx_device_info(self.h, C.byref(ncu), C.byref(hbm), name, 256), "mcx_device_info")
+        return {"n_cu": ncu.value, "hbm_bytes": hbm.value, "name": name.value.decode()}
+
+    # ---- K1 ------------------------------------------------------------------------------------------------------
+    def sim_create(self, plan):
+        out = C.c_void_p()
+        self._check(self.lib.mcx_sim_create(self.h, C.byref(plan.desc), C.byref(out)), "mcx_sim_create")
+        return _Owned(out, self.lib.mcx_sim_destroy, plan)
+
+    def generate_paths(self, sim, seed: int, path_offset: int, n_paths: int, inject_z=None, inject_u=None,
+                       out: torch.Tensor | None = None) -> torch.Tensor:
+        plan = sim.plan
+        if out is None:
+            out = self.empty(plan.n_dates, plan.n_state, n_paths)
+        assert out.is_contiguous() and out.shape == (plan.n_dates, plan.n_state, n_paths)
+        if inject_z is not None:
+            assert inject_z.is_contiguous() and inject_z.shape == (plan.n_steps, plan.n_z, n_paths)
+        if inject_u is not None:
+            assert inject_u.is_contiguous() and inject_u.shape == (plan.n_steps, n_paths)
+        self._check(self.lib.mcx_generate_paths(
+            self.h, sim.ptr, C.c_uint64(seed), C.c_uint64(path_offset), C.c_int64(n_paths), C.c_int64(n_paths),
+            _vp(out.data_ptr()), _vp(inject_z.data_ptr() if inject_z is not None else 0),
+            _vp(inject_u.data_ptr() if inject_u is not None else 0), self._stream()), "mcx_generate_paths")
+        return out
+
+    # ---- K2 ------------------------------------------------------------------------------------------------------
+    def book_create(self, plan):
+        out = C.c_void_p()
+        self._check(self.lib.mcx_book_create(self.h, C.byref(plan.desc), C.byref(out)), "mcx_book_create")
+        return _Owned(out, self.lib.mcx_book_destroy, plan)
+
+    def book_set_coeffs(self, book, offset: int, values: np.ndarray):
+        v = np.ascontiguousarray(values, dtype=np.float64).reshape(-1)
+        book.plan.coeffs[offset:offset + v.size] = v
+        self._check(self.lib.mcx_book_set_coeffs(self.h, book.ptr, C.c_int64(offset), C.c_int64(v.size), _abi.ptr(v),
+                                                 self._stream()), "mcx_book_set_coeffs")
+
+    def eval_book(self, book, paths: torch.Tensor):
+        plan = book.plan
+        n = paths.shape[2]
+        cfs = self.empty(plan.n_netting_sets, n) if plan.desc.want_cfs else None
+        expo = self.empty(plan.n_netting_sets, plan.n_expo_rows, n) if plan.desc.want_expo else None
+        self._check(self.lib.mcx_eval_book(
+            self.h, book.ptr, _vp(paths.data_ptr()), C.c_int64(n), C.c_int64(n),
+            _vp(cfs.data_ptr() if cfs is not None else 0), _vp(expo.data_ptr() if expo is not None else 0),
+            C.c_int64(n), self._stream()), "mcx_eval_book")
+        return cfs, expo
+
+    def resolve_atoms(self, book, atom_ids, paths: torch.Tensor) -> torch.Tensor:
+        ids = np.ascontiguousarray(atom_ids, dtype=np.int32)
+        n = paths.shape[2]
+        out = self.empty(len(ids), n)
+        self._check(self.lib.mcx_resolve_atoms(self.h, book.ptr, _abi.ptr(ids), C.c_int32(len(ids)),
+                                               _vp(paths.data_ptr()), C.c_int64(n), C.c_int64(n), _vp(out.data_ptr()),
+                                               C.c_int64(n), self._stream()), "mcx_resolve_atoms")
+        return out
+
+    # ---- K3 ------------------------------------------------------------------------------------------------------
+    def lsm_stats(self, book, atom_ids, paths: torch.Tensor) -> np.ndarray:
+        ids = np.ascontiguousarray(atom_ids, dtype=np.int32)
+        n = paths.shape[2]
+        out = np.zeros((len(ids), 2))
+        self._check(self.lib.mcx_lsm_stats(self.h, book.ptr, _abi.ptr(ids), C.c_int32(len(ids)), _vp(paths.data_ptr()),
+                                           C.c_int64(n), C.c_int64(n), _abi.ptr(out), self._stream()), "mcx_lsm_stats")
+        return out
+
+    def lsm_step(self, book, product: int, roll_begin: int, roll_end: int, num_atom: int, x_atom: int, shift: float,
+                 scale: float, paths: torch.Tensor, W: torch.Tensor, flags: int = 0) -> torch.Tensor:
+        n = paths.shape[2]
+        K = book.plan.n_basis
+        S = W.shape[0]
+        moments = self.empty((2 * K - 1) + S * K)
+        self._check(self.lib.mcx_lsm_step(
+            self.h, book.ptr, C.c_int32(product), C.c_int32(roll_begin), C.c_int32(roll_end), C.c_int32(num_atom),
+            C.c_int32(x_atom), C.c_double(shift), C.c_double(scale), _vp(paths.data_ptr()), C.c_int64(n), C.c_int64(n),
+            _vp(W.data_ptr()), C.c_int64(W.shape[1]), _vp(moments.data_ptr()), C.c_int32(int(flags)), self._stream()),
+            "mcx_lsm_step")
+        return moments
+
+    # ---- K4 / K5 -------------------------------------------------------------------------------------------------
+    def reduce_vector(self, x: torch.Tensor) -> np.ndarray:
+        out = np.zeros(1, dtype=_abi.ACC_DTYPE)
+        self._check(self.lib.mcx_reduce_vector(self.h, _vp(x.data_ptr()), C.c_int64(x.shape[0]), _abi.ptr(out),
+                                               self._stream()), "mcx_reduce_vector")
+        return out
+
+    def reduce_profiles(self, unsec, expo_ns: torch.Tensor) -> np.ndarray:
+        n = expo_ns.shape[1]
+        out = np.zeros((unsec.n_dates, 2), dtype=_abi.ACC_DTYPE)
+        self._check(self.lib.mcx_reduce_profiles(self.h, C.byref(unsec.desc), _vp(expo_ns.data_ptr()), C.c_int64(n),
+                                                 C.c_int64(n), _abi.ptr(out), self._stream()), "mcx_reduce_profiles")
+        return out
+
+    def reduce_cva(self, book, unsec, surv_atoms, cond_atoms, recovery: float, expo_ns: torch.Tensor,
+                   paths: torch.Tensor) -> np.ndarray:
+        n = expo_ns.shape[1]
+        sa = np.ascontiguousarray(surv_atoms, dtype=np.int32)
+        ca = np.ascontiguousarray(cond_atoms, dtype=np.int32)
+        out = np.zeros(1, dtype=_abi.ACC_DTYPE)
+        self._check(self.lib.mcx_reduce_cva(
+            self.h, book.ptr, C.byref(unsec.desc), _abi.ptr(sa), _abi.ptr(ca), C.c_double(recovery),
+            _vp(expo_ns.data_ptr()), _vp(paths.data_ptr()), C.c_int64(n), C.c_int64(n), C.c_int64(paths.shape[2]),
+            _abi.ptr(out), self._stream()), "mcx_reduce_cva")
+        return out
+
+    def unsecured(self, unsec, expo_ns: torch.Tensor) -> torch.Tensor:
+        n = expo_ns.shape[1]
+        out = self.empty(unsec.n_dates, n)
+        self._check(self.lib.mcx_unsecured(self.h, C.byref(unsec.desc), _vp(expo_ns.data_ptr()), C.c_int64(n),
+                                           C.c_int64(n), _vp(out.data_ptr()), C.c_int64(n), self._stream()),
+                    "mcx_unsecured")
+        return out
+
+    def select_hist(self, unsec, expo_ns: torch.Tensor, n_sel: int, prefix: np.ndarray, shift: int, bits: int) -> torch.Tensor:
+        n = expo_ns.shape[1]
+        pf = np.ascontiguousarray(prefix, dtype=np.uint64)
+        hist = self.empty(unsec.n_dates, n_sel, 1 << bits, dtype=torch.int64)
+        self._check(self.lib.mcx_select_hist(self.h, C.byref(unsec.desc), _vp(expo_ns.data_ptr()), C.c_int64(n),
+                                             C.c_int64(n), C.c_int32(n_sel), _abi.ptr(pf), C.c_int32(shift),
+                                             C.c_int32(bits), _vp(hist.data_ptr()), self._stream()), "mcx_select_hist")
+        return hist
+
+
+class _Owned:
+    """native object + the plan whose host arrays it was built from"""
+
+    def __init__(self, ptr, destroy, plan):
+        self.ptr, self._destroy, self.plan = ptr, destroy, plan
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self._destroy(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+_default_backend = None
+
+
+def get_backend():
+    """the process-wide HIP backend (created on first use; raises if the extension or the GPU is missing)"""
+    global _default_backend
+    if _default_backend is None:
+        _default_backend = HipBackend()
+    return _default_backend
+
+
+def set_backend(backend):
+    """tests install the CPU oracle here as the CHECKER of host logic; the product never does."""
+    global _default_backend
+    _default_backend = backend

@@ -1,0 +1,520 @@
+"""SimulationController — host orchestration of the MI355X Monte-Carlo path
+(reference surface: controller/controller.py:21-709; same constructor, same run_simulation() -> SimulationResults).
+
+What stays on the host (µs–ms): timeline unions keyed on exact floats, request/atom planning, the K x K regression
+solves, metric finalisation.  What runs as hand-written HIP behind the C ABI (include/mcx.h):
+  K1 path generation, K2 book evaluation (resolve + cashflows + exposures), K3 LSM normal equations,
+  K4 EE/ENE/PV/CVA reductions, K5 PFE radix select.
+Paths are sharded over the ranks of torch.distributed (one process per GPU); only accumulator records, normal equations
+and select histograms cross GPUs (mcx/parallel.py)."""
+from __future__ import annotations
+
+import logging
+import math
+import time
+from collections import defaultdict
+from typing import Sequence
+
+import numpy as np
+import torch
+
+from .. import _abi, _native
+from ..common.enums import SimulationScheme
+from ..common.packages import FLOAT, device
+from ..engine.engine import MonteCarloEngine
+from ..maths.regression import PolyomialRegression, RegressionFunction
+from ..metrics.metric import Metric, MetricType, mean_and_error
+from ..metrics.risk_metrics import PathwisePrimitive, RiskMetrics
+from ..models.model import Model
+from ..models.model_config import ModelConfig
+from ..parallel import Shard
+from ..plan import BookCompiler, BookPlan, SimPlan, UnsecuredSpec, solve_normal_equations
+from ..products.netting_set import NettingSet
+from ..products.product import Product
+from ..request_interface.request_interface import RequestInterface
+from ..request_interface.request_types import AtomicRequest, AtomicRequestType
+from .simulation_results import SimulationResults
+
+logger = logging.getLogger(__name__)
+
+_SELECT_DIGITS = ((53, 11), (42, 11), (31, 11), (20, 11), (9, 11), (0, 9))
+
+
+def _key_to_double(keys: np.ndarray) -> np.ndarray:
+    keys = np.asarray(keys, dtype=np.uint64)
+    top = np.uint64(1) << np.uint64(63)
+    bits = np.where(keys & top, keys ^ top, ~keys)
+    return bits.view(np.float64)
+
+
+class SimulationController:
+    def __init__(self, netting_sets: Sequence[NettingSet], model: Model, risk_metrics: RiskMetrics,
+                 num_paths_mainsim: int, num_paths_presim: int, num_steps: int, simulation_scheme: SimulationScheme,
+                 differentiate: bool = False, regression_function: RegressionFunction = PolyomialRegression(degree=2),
+                 *, backend=None, use_mfma: bool = False):
+        self.risk_metrics = risk_metrics
+        netting_sets = list(netting_sets)
+        if len(netting_sets) == 0:
+            raise ValueError("Provide at least one netting set.")
+        seen: set[int] = set()
+        for ns in netting_sets:
+            for p in ns.products:
+                if id(p) in seen:
+                    raise ValueError("A product instance cannot belong to more than one netting set.")
+                seen.add(id(p))
+        products = [p for ns in netting_sets for p in ns.products]
+        self.netting_sets = netting_sets
+        self.product_to_netting_set_idx = [i for i, ns in enumerate(netting_sets) for _ in ns.products]
+
+        self.metric_exposure_timeline = risk_metrics.exposure_timeline.clone()
+        self.exposure_timeline = self._build_internal_exposure_timeline()
+        self._exposure_time_to_idx = {float(t): i for i, t in enumerate(self.exposure_timeline)}
+        self.metric_exposure_indices = torch.tensor(
+            [self._exposure_time_to_idx[float(t)] for t in self.metric_exposure_timeline], dtype=torch.long)
+        self.netting_set_delayed_exposure_indices = self._build_netting_set_delayed_exposure_indices()
+
+        self.numeraire_requests = {(float(t), "numeraire"): AtomicRequest(AtomicRequestType.NUMERAIRE, time1=float(t))
+                                   for t in self.exposure_timeline}
+        self.spot_requests = {(float(t), a): AtomicRequest(AtomicRequestType.SPOT)
+                              for p in products for a in p.asset_ids for t in self.exposure_timeline}
+        if risk_metrics.any_xva:
+            if not isinstance(model, ModelConfig):
+                raise Exception("ModelConfig needs to be provided for xVA valuation.")
+            if not all(cp in model.id_to_model for cp in risk_metrics.counterparty_ids):
+                raise Exception("Not all models set for xVA valuation.")
+
+        self.products = products
+        self.model = model
+        self.num_paths_presim = int(num_paths_presim)
+        self.num_paths_mainsim = int(num_paths_mainsim)
+        self.num_steps = int(num_steps)
+        self.simulation_scheme = simulation_scheme
+        self.differentiate = differentiate
+        self.regression_function = regression_function
+        self.requires_higher_order_derivatives = False
+        self.use_mfma = use_mfma
+        # the reference accumulates LSM cashflows in a float32 cache (controller.py:312-330); reproduce it for parity
+        self.reference_float32_cf_cache = True
+        self._backend = backend
+        for i, p in enumerate(products):
+            p.product_id = i
+        if differentiate:
+            self.model.requires_grad()
+
+        K = regression_function.get_degree()
+        if K > _abi.MAX_BASIS:
+            raise ValueError(f"regression basis size {K} exceeds MCX_MAX_BASIS={_abi.MAX_BASIS}")
+        self.regression_coeffs = []
+        for p in products:
+            p._allocate_regression_coeffs(regression_function)
+            if p.get_num_states() > _abi.MAX_STATES:
+                raise ValueError("too many exercise states")
+            self.regression_coeffs.append(torch.zeros((len(self.exposure_timeline), p.get_num_states(), K), dtype=FLOAT))
+
+        prod_times = {float(t) for p in products for t in p.modeling_timeline}
+        exposure_times = {float(t) for t in self.exposure_timeline}
+        self.simulation_timeline = torch.tensor(sorted(prod_times | exposure_times), dtype=FLOAT, device=device)
+        self.requires_regression = any(self._product_requires_regression(p) for p in products)
+        self.timings: dict[str, float] = {}
+        self.last_state: dict = {}       # device buffers of the last run (paths / cfs / exposures) for inspection
+        self._inject = {}                # tests: {"pre": (z, u), "main": (z, u)} recorded reference draws
+
+    # ---- planning (host) -----------------------------------------------------------------------------------------
+    @property
+    def backend(self):
+        if self._backend is None:
+            self._backend = _native.get_backend()
+        return self._backend
+
+    def _build_internal_exposure_timeline(self) -> torch.Tensor:
+        rm = self.risk_metrics
+        if not rm.requires_exposure_profiles():
+            return rm.exposure_timeline.clone()
+        times = {float(t) for t in rm.exposure_timeline}
+        for ns in self.netting_sets:
+            if ns.is_collateralized():
+                times.update(float(t) for t in ns.get_collateral_query_times(rm.exposure_timeline))
+        return torch.tensor(sorted(times), dtype=FLOAT, device=device)
+
+    def _build_netting_set_delayed_exposure_indices(self) -> list[torch.Tensor]:
+        out = []
+        for ns in self.netting_sets:
+            idx = torch.full((len(self.metric_exposure_timeline),), -1, dtype=torch.long)
+            if ns.is_collateralized():
+                delayed = self.metric_exposure_timeline - ns.margin_period_of_risk
+                for m, t in enumerate(delayed):
+                    if float(t) >= 0.0:
+                        idx[m] = self._exposure_time_to_idx[float(t)]
+            out.append(idx)
+        return out
+
+    @staticmethod
+    def _make_unique_names(base_names: list[str]) -> list[str]:
+        counts: dict[str, int] = defaultdict(int)
+        out = []
+        for b in base_names:
+            counts[b] += 1
+            out.append(b if counts[b] == 1 else f"{b}#{counts[b]}")
+        return out
+
+    def _can_use_analytic_exposure_for_product(self, product: Product) -> bool:
+        ok = {MetricType.PV, MetricType.EPE, MetricType.PFE}
+        return all(m.metric_type in ok for m in self.risk_metrics.metrics) and product.supports_analytic_exposure(self.model)
+
+    def _product_requires_regression(self, product: Product) -> bool:
+        if len(product.regression_timeline) > 0:
+            return True
+        if not self.risk_metrics.requires_exposure_profiles():
+            return False
+        return not self._can_use_analytic_exposure_for_product(product)
+
+    def _can_skip_monte_carlo_for_product(self, product: Product) -> bool:
+        if self.risk_metrics.requires_exposure_profiles():
+            return False
+        return all(m.metric_type == MetricType.PV and m.evaluation_type == Metric.EvaluationType.ANALYTICAL
+                   and product.supports_analytic_pv(self.model) for m in self.risk_metrics.metrics)
+
+    def _get_requests(self):
+        reqs = defaultdict(set)
+        for label, r in self.numeraire_requests.items():
+            reqs[label].add(r)
+        for label, r in self.spot_requests.items():
+            reqs[label].add(r)
+        for m in self.risk_metrics.metrics:
+            for label, rs in m.get_requests().items():
+                reqs[label].update(rs)
+        return reqs
+
+    def compute_higher_derivatives(self):
+        self.requires_higher_order_derivatives = True
+
+    def _compile(self):
+        """objects -> descriptors (BookPlan) + bookkeeping of coefficient offsets / metric atoms"""
+        rm = self.risk_metrics
+        sim_tl = [float(t) for t in self.simulation_timeline]
+        K = self.regression_function.get_degree()
+        comp = BookCompiler(self.model, sim_tl, K)
+        E = len(self.exposure_timeline)
+        expo_times = [float(t) for t in self.exposure_timeline]
+        want_expo = rm.requires_exposure_profiles()
+        want_cfs = rm.requires_discounted_cashflows()
+        prods = np.zeros(len(self.products), dtype=_abi.PRODUCT_DTYPE)
+        self._expo_coeff_base, self._reg_coeff_base, self._cash_meta = [], [], []
+        self._mc_products = []
+        off = 0
+        for p_i, p in enumerate(self.products):
+            S = p.get_num_states()
+            self._expo_coeff_base.append(off)
+            off += E * S * K
+            self._reg_coeff_base.append(off)
+            off += len(p.regression_timeline) * S * K
+        for p_i, p in enumerate(self.products):
+            S = p.get_num_states()
+            skip = self._can_skip_monte_carlo_for_product(p)
+            cash = [] if skip else p._cash_events(comp)
+            pdates = [float(t) for t in p.product_timeline]
+            assert skip or len(cash) == len(pdates)
+
+            def emit_cash(ce):
+                num = comp.atom(AtomicRequest(AtomicRequestType.NUMERAIRE, ce.time), "numeraire", ce.time)
+                x = comp.atom(AtomicRequest(AtomicRequestType.SPOT), ce.x_asset, ce.time) if ce.kind == _abi.EV_EXERCISE else -1
+                co = -1 if ce.reg_idx is None else self._reg_coeff_base[p_i] + ce.reg_idx * S * K
+                return comp.add_event(ce.kind, comp.tidx(ce.time), num, x, comp.add_terms(ce.terms), co, -1, ce.strike, ce.sign)
+
+            cf_begin = len(comp.events)
+            for ce in cash:
+                emit_cash(ce)
+            cf_end = len(comp.events)
+            ev_begin = len(comp.events)
+            if not skip:
+                t_start = 0
+                if want_expo:
+                    analytic = self._can_use_analytic_exposure_for_product(p)
+                    for i, t in enumerate(expo_times):
+                        while t_start < len(pdates) and pdates[t_start] <= t:            # controller.py:417-426
+                            emit_cash(cash[t_start])
+                            t_start += 1
+                        num = comp.atom(self.numeraire_requests[(t, "numeraire")], "numeraire", t)
+                        x = comp.atom(self.spot_requests[(t, p.asset_ids[0])], p.asset_ids[0], t)
+                        if analytic:
+                            aux = (self.model._pf(1), self.model._pf(2), float(p.exercise_date[0]) - t, 0.0)
+                            comp.add_event(_abi.EV_EXPO_BS, comp.tidx(t), num, x, (0, 0), -1, i, p._K, p._sign(), aux)
+                        else:
+                            comp.add_event(_abi.EV_EXPO_POLY, comp.tidx(t), num, x, (0, 0),
+                                           self._expo_coeff_base[p_i] + i * S * K, i)
+                if want_cfs or not want_expo:
+                    while t_start < len(pdates):                                          # controller.py:401-410, 451-461
+                        emit_cash(cash[t_start])
+                        t_start += 1
+                self._mc_products.append(p_i)
+            ev_end = len(comp.events)
+            prods[p_i] = (ev_begin, ev_end, cf_begin, cf_end, self.product_to_netting_set_idx[p_i],
+                          p.get_initial_state(), S, 0)
+        # CVA survival atoms (cva_metric.py:23-46)
+        self._cva_atoms = {}
+        mt = [float(t) for t in self.metric_exposure_timeline]
+        for m_i, m in enumerate(rm.metrics):
+            if m.metric_type == MetricType.CVA and m._native:
+                surv, cond = [], []
+                for k in range(len(mt) - 1):
+                    label = (k, m.counterparty_id)
+                    surv.append(comp.atom(m.survival_prob_requests[label], m.counterparty_id, mt[k]))
+                    cond.append(comp.atom(m.cond_survival_prob_requests[label], m.counterparty_id, mt[k]))
+                self._cva_atoms[m_i] = (surv, cond)
+        self._comp = comp
+        n_state = sum(s.state_dim for s in self.model._slots())
+        self._plan_args = (prods, len(self.netting_sets), E if want_expo else 0, off, want_cfs, want_expo, n_state)
+
+    # ---- pre-simulation: Longstaff-Schwartz (controller.py:272-383) ----------------------------------------------
+    def _regression_schedule(self, p_i: int, product: Product):
+        """backward list of (t_reg, roll_begin, roll_end, store_prod_idx|None, store_expo_idx|None)"""
+        pdates = [float(t) for t in product.product_timeline]
+        preg = [float(t) for t in product.regression_timeline]
+        reg_tl = sorted(set(preg) | {float(t) for t in self.exposure_timeline})
+        P = len(pdates)
+        last = P
+        sched = []
+        for t_reg in reversed(reg_tl):
+            idx = int(np.searchsorted(np.asarray(pdates), t_reg, side="left"))
+            if idx >= P:
+                continue
+            t_next = idx + 1 if pdates[idx] == t_reg else idx
+            roll = (t_next, last) if t_next < last else (last, last)
+            if t_next < last:
+                last = t_next
+            sched.append((t_reg, roll[0], roll[1], preg.index(t_reg) if t_reg in preg else None,
+                          self._exposure_time_to_idx.get(t_reg)))
+        return sched
+
+    def _perform_regression(self, shard: Shard, sim_plan: SimPlan, sim):
+        be = self.backend
+        off, n_local = shard.split(self.num_paths_presim)
+        eng = MonteCarloEngine(self.simulation_timeline, self.simulation_scheme, self.model, n_local, self.num_steps,
+                               is_pre_simulation=True, path_offset=off, backend=be, plan=sim_plan, sim=sim)
+        if "pre" in self._inject:
+            eng.inject_z, eng.inject_u = self._inject["pre"]
+        paths = eng.generate_paths_native()
+        self.last_state["paths_pre"] = paths
+        K = self.regression_function.get_degree()
+        comp = self._comp
+        jobs = []
+        for p_i, p in enumerate(self.products):
+            if not self._product_requires_regression(p) or p_i not in self._mc_products:
+                continue
+            sched = self._regression_schedule(p_i, p)
+            atoms = []
+            for (t_reg, *_rest) in sched:
+                num = comp.atom(AtomicRequest(AtomicRequestType.NUMERAIRE, t_reg), "numeraire", t_reg)
+                x = comp.atom(AtomicRequest(AtomicRequestType.SPOT), p.asset_ids[0], t_reg)
+                atoms.append((num, x))
+            jobs.append((p_i, p, sched, atoms))
+        if len(self._comp.atoms) != len(self.book_plan.atoms):
+            raise RuntimeError("internal: regression atoms must be registered before the book is frozen")
+        # range of every explanatory variable (conditioning of the monomial basis; exact-degeneracy detection)
+        x_ids = sorted({x for _, _, _, atoms in jobs for _, x in atoms})
+        if x_ids:
+            mm = be.lsm_stats(self.book, x_ids, paths)
+            g = shard.all_gather_np(mm)
+            lo, hi = g[:, :, 0].min(axis=0), g[:, :, 1].max(axis=0)
+            x_range = {x: (lo[i], hi[i]) for i, x in enumerate(x_ids)}
+        lsm_flags = (_abi.LSM_MFMA if self.use_mfma else 0) | (_abi.LSM_F32_CACHE if self.reference_float32_cf_cache else 0)
+        for p_i, p, sched, atoms in jobs:
+            S = p.get_num_states()
+            W = be.zeros(S, n_local)
+            for (t_reg, r0, r1, prod_idx, expo_idx), (num, x) in zip(sched, atoms):
+                xmin, xmax = x_range[x]
+                degenerate = not (xmax > xmin)
+                shift = 0.5 * (xmin + xmax) if not degenerate else xmin
+                scale = 2.0 / (xmax - xmin) if not degenerate else 1.0
+                mom = be.lsm_step(self.book, p_i, r0, r1, num, x, shift, scale, paths, W, flags=lsm_flags)
+                shard.all_reduce_(mom)
+                coeffs = solve_normal_equations(mom.detach().cpu().numpy(), K, S, shift, scale, degenerate, xmin)
+                if prod_idx is not None:
+                    p.regression_coeffs[prod_idx] = torch.from_numpy(coeffs)
+                    be.book_set_coeffs(self.book, self._reg_coeff_base[p_i] + prod_idx * S * K, coeffs)
+                if expo_idx is not None:
+                    self.regression_coeffs[p_i][expo_idx] = torch.from_numpy(coeffs)
+                    be.book_set_coeffs(self.book, self._expo_coeff_base[p_i] + expo_idx * S * K, coeffs)
+
+    def _register_regression_atoms(self):
+        """atoms the LSM needs must exist before the book is uploaded"""
+        for p_i, p in enumerate(self.products):
+            if self._product_requires_regression(p) and p_i in self._mc_products:
+                for (t_reg, *_r) in self._regression_schedule(p_i, p):
+                    self._comp.atom(AtomicRequest(AtomicRequestType.NUMERAIRE, t_reg), "numeraire", t_reg)
+                    self._comp.atom(AtomicRequest(AtomicRequestType.SPOT), p.asset_ids[0], t_reg)
+
+    def perform_prepocessing(self, request_interface: RequestInterface):   # (sic) reference spelling
+        request_interface.collect_and_index_requests(self.products, self.simulation_timeline, self._get_requests(),
+                                                     self.metric_exposure_timeline)
+
+    # ---- main simulation: metrics (controller.py:506-563) ----------------------------------------------------------
+    def _zero_metric_result(self, metric: Metric):
+        n = 1 if metric.metric_type in {MetricType.PV, MetricType.CVA, MetricType.EEPE} else len(self.metric_exposure_timeline)
+        return [(0.0, 0.0) for _ in range(n)]
+
+    def _select_order_stats(self, shard: Shard, unsec: UnsecuredSpec, expo_ns, ranks: list[int]) -> np.ndarray:
+        """exact global order statistics x_(r) for r in ranks at every metric date -> [n_dates][len(ranks)]"""
+        be = self.backend
+        E, n_sel = unsec.n_dates, len(ranks)
+        prefix = np.zeros((E, n_sel), dtype=np.uint64)
+        rem = np.tile(np.asarray(ranks, dtype=np.int64), (E, 1))
+        for shift, bits in _SELECT_DIGITS:
+            hist = be.select_hist(unsec, expo_ns, n_sel, prefix, shift, bits)
+            shard.all_reduce_(hist)
+            cum = np.cumsum(hist.cpu().numpy(), axis=-1)
+            b = (cum <= rem[..., None]).sum(axis=-1)
+            below = np.where(b > 0, np.take_along_axis(cum, np.maximum(b - 1, 0)[..., None], axis=-1)[..., 0], 0)
+            rem = rem - below
+            prefix = prefix | (b.astype(np.uint64) << np.uint64(shift))
+        return _key_to_double(prefix)
+
+    def _evaluate_netting_set(self, shard: Shard, ns_i: int, ns: NettingSet, cfs, expo, paths, has_pathwise: bool,
+                              analytical_acc: list[float]):
+        be, rm = self.backend, self.risk_metrics
+        n_total = self.num_paths_mainsim
+        want_expo = rm.requires_exposure_profiles()
+        unsec = None
+        expo_ns = None
+        if want_expo:
+            delayed = self.netting_set_delayed_exposure_indices[ns_i].numpy() if ns.is_collateralized() else None
+            unsec = UnsecuredSpec(self.metric_exposure_indices.numpy(), delayed, ns.threshold, ns.is_collateralized())
+            expo_ns = expo[ns_i]
+        prof = None
+
+        def profiles():
+            nonlocal prof
+            if prof is None:
+                local = be.reduce_profiles(unsec, expo_ns).view(np.float64).reshape(unsec.n_dates, 2, 4)
+                prof = shard.all_gather_np(local)          # [world][E][2][4]
+            return prof
+
+        out = []
+        for m_i, metric in enumerate(rm.metrics):
+            mt = metric.metric_type
+            if mt == MetricType.CVA and ns.counterparty_id is not None \
+                    and getattr(metric, "counterparty_id", None) != ns.counterparty_id:
+                out.append(self._zero_metric_result(metric))                           # controller.py:536-542
+                continue
+            if mt == MetricType.PV and metric.evaluation_type == Metric.EvaluationType.ANALYTICAL:
+                val, err = 0.0, 0.0
+                if has_pathwise:
+                    val, err = mean_and_error(shard.all_gather_np(be.reduce_vector(cfs[ns_i]).view(np.float64)))
+                out.append([(analytical_acc[m_i] + val, err)])
+                continue
+            if not metric._native:
+                out.append(self._evaluate_plugin_metric(metric, ns, unsec, expo_ns, cfs, ns_i, paths))
+                continue
+            if mt == MetricType.PV:
+                out.append([mean_and_error(shard.all_gather_np(be.reduce_vector(cfs[ns_i]).view(np.float64)))])
+            elif mt == MetricType.EPE:
+                out.append([mean_and_error(profiles()[:, m, 0]) for m in range(unsec.n_dates)])
+            elif mt == MetricType.ENE:
+                out.append([mean_and_error(profiles()[:, m, 1]) for m in range(unsec.n_dates)])
+            elif mt == MetricType.CE:
+                out.append([mean_and_error(profiles()[:, 0, 0])])
+            elif mt == MetricType.EEPE:
+                ee = np.array([mean_and_error(profiles()[:, m, 0])[0] for m in range(unsec.n_dates)])
+                err = float(np.std(ee, ddof=1) / math.sqrt(len(ee))) if len(ee) > 1 else float("nan")
+                out.append([(float(ee.mean()), err)])
+            elif mt == MetricType.CVA:
+                surv, cond = self._cva_atoms[m_i]
+                rec = be.reduce_cva(self.book, unsec, surv, cond, metric.recovery_rate, expo_ns, paths)
+                out.append([mean_and_error(shard.all_gather_np(rec.view(np.float64)))])
+            elif mt == MetricType.PFE:
+                q = metric.q_index(n_total)
+                edge = q == 0 or q == n_total - 1
+                ranks = [q] if edge else [q - 1, q, q + 1]
+                vals = self._select_order_stats(shard, unsec, expo_ns, ranks)
+                res = []
+                for m in range(unsec.n_dates):
+                    if edge:
+                        res.append((float(vals[m, 0]), 0.0))
+                    else:
+                        lo, mid, hi = (float(v) for v in vals[m])
+                        res.append((mid, metric.quantile_error(lo, mid, hi, q, n_total)))
+                out.append(res)
+            else:
+                raise NotImplementedError(mt)
+        return out
+
+    def _evaluate_plugin_metric(self, metric, ns, unsec, expo_ns, cfs, ns_i, paths):
+        """user-defined Metric subclass: hand it torch views of the device buffers (Metrics API, metric.py:37-60)"""
+        be = self.backend
+        exposures = []
+        if unsec is not None:
+            u = be.unsecured(unsec, expo_ns)
+            exposures = [u[m] for m in range(unsec.n_dates)]
+        cf = cfs[ns_i] if cfs is not None else be.zeros(paths.shape[2])
+        ri = RequestInterface(self.model)
+        self.perform_prepocessing(ri)
+        resolved = ri.resolve_requests(paths.permute(2, 0, 1))
+        res = metric.evaluate(exposures=exposures, cfs=cf, resolved_requests=resolved, netting_set=ns, model=self.model)
+        return [(float(v), float(e)) for v, e in res]
+
+    # ---- entry point (controller.py:663-709) ------------------------------------------------------------------------
+    def run_simulation(self) -> SimulationResults:
+        if self.differentiate:
+            from ..aad import run_with_tangents
+            return run_with_tangents(self)
+        t0 = time.perf_counter()
+        be = self.backend
+        shard = Shard()
+        self._compile_all()
+        sim_plan = SimPlan(self.model, self.simulation_timeline.numpy(), self.simulation_scheme, self.num_steps)
+        sim = be.sim_create(sim_plan)
+        self.sim_plan = sim_plan
+        if self.requires_regression:
+            self._perform_regression(shard, sim_plan, sim)
+        be.synchronize()
+        t1 = time.perf_counter()
+
+        off, n_local = shard.split(self.num_paths_mainsim)
+        eng = MonteCarloEngine(self.simulation_timeline, self.simulation_scheme, self.model, n_local, self.num_steps,
+                               is_pre_simulation=False, path_offset=off, backend=be, plan=sim_plan, sim=sim)
+        if "main" in self._inject:
+            eng.inject_z, eng.inject_u = self._inject["main"]
+        self._main_engine = eng
+        paths = eng.generate_paths_native()
+        be.synchronize()
+        t2 = time.perf_counter()
+        cfs, expo = be.eval_book(self.book, paths) if self._mc_products else (None, None)
+        be.synchronize()
+        t3 = time.perf_counter()
+        self.last_state.update(paths=paths, cfs=cfs, expo=expo)
+        results = self._evaluate_all(shard, cfs, expo, paths)
+        t4 = time.perf_counter()
+        self.timings = dict(preprocessing=t1 - t0, path_generation=t2 - t1, request_resolution=0.0,
+                            valuation=t3 - t2, metrics=t4 - t3, total=t4 - t0)
+        logger.info("Simulation completed for %d netting set(s) and %d product(s): preprocessing=%.6fs "
+                    "path_generation=%.6fs request_resolution=%.6fs valuation=%.6fs total=%.6fs",
+                    len(self.netting_sets), len(self.products), t1 - t0, t2 - t1, 0.0, t4 - t2, t4 - t0)
+        return self._package(results, [], [])
+
+    def _compile_all(self):
+        """objects -> descriptors, LSM atoms registered before the plan is frozen and uploaded"""
+        self._compile()
+        if self.requires_regression:
+            self._register_regression_atoms()
+        self.book_plan = BookPlan(self._comp, *self._plan_args)
+        self.book = self.backend.book_create(self.book_plan)
+
+    def _evaluate_all(self, shard, cfs, expo, paths):
+        analytical = [[0.0 for _ in self.risk_metrics.metrics] for _ in self.netting_sets]
+        has_pathwise = [False] * len(self.netting_sets)
+        for p_i, p in enumerate(self.products):
+            ns_i = self.product_to_netting_set_idx[p_i]
+            if self._can_skip_monte_carlo_for_product(p):
+                for m_i, m in enumerate(self.risk_metrics.metrics):
+                    analytical[ns_i][m_i] += float(m.evaluate_analytically(product=p, model=self.model)[0][0])
+            else:
+                has_pathwise[ns_i] = True
+        return [self._evaluate_netting_set(shard, i, ns, cfs, expo, paths, has_pathwise[i], analytical[i])
+                for i, ns in enumerate(self.netting_sets)]
+
+    def _package(self, results, grads, higher):
+        return SimulationResults(
+            results, grads, higher,
+            netting_set_names=self._make_unique_names([ns.get_name() for ns in self.netting_sets]),
+            metric_names=self._make_unique_names([m.get_name() for m in self.risk_metrics.metrics]),
+            model_param_names=self.model.get_model_param_names())

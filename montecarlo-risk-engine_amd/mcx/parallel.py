@@ -1,0 +1,61 @@
+"""Path sharding across the GPUs of one node: one process per GPU, torch.distributed over RCCL (backend "nccl" on ROCm)
+or gloo (CPU tests).  Paths are independent, so no path data ever crosses GPUs; only accumulator records, LSM normal
+equations and radix-select histograms are exchanged."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+class Shard:
+    """global path range of this rank: contiguous, remainder spread over the first ranks"""
+
+    def __init__(self, group=None):
+        self.active = dist.is_available() and dist.is_initialized()
+        self.group = group
+        self.rank = dist.get_rank(group) if self.active else 0
+        self.world = dist.get_world_size(group) if self.active else 1
+        self.backend = dist.get_backend(group) if self.active else None
+
+    def split(self, n_total: int) -> tuple[int, int]:
+        base, rem = divmod(int(n_total), self.world)
+        count = base + (1 if self.rank < rem else 0)
+        offset = self.rank * base + min(self.rank, rem)
+        return offset, count
+
+    def _comm_device(self, like: torch.Tensor | None = None):
+        if self.backend == "nccl":
+            return like.device if like is not None and like.is_cuda else torch.device("cuda", torch.cuda.current_device())
+        return torch.device("cpu")
+
+    def all_reduce_(self, t: torch.Tensor) -> torch.Tensor:
+        """in-place sum over ranks of a device (nccl) or host (gloo) tensor"""
+        if not self.active or self.world == 1:
+            return t
+        dev = self._comm_device(t)
+        if t.device == dev:
+            dist.all_reduce(t, group=self.group)
+            return t
+        tmp = t.to(dev)
+        dist.all_reduce(tmp, group=self.group)
+        t.copy_(tmp)
+        return t
+
+    def all_reduce_np(self, a: np.ndarray) -> np.ndarray:
+        if not self.active or self.world == 1:
+            return a
+        t = torch.from_numpy(np.ascontiguousarray(a)).to(self._comm_device())
+        dist.all_reduce(t, group=self.group)
+        return t.cpu().numpy()
+
+    def all_gather_np(self, a: np.ndarray) -> np.ndarray:
+        """stack equal-shaped float64 arrays of all ranks along a new leading axis (the single small collective that
+        carries the (n, shift, s1, s2) accumulator records of every metric)"""
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        if not self.active or self.world == 1:
+            return a[None]
+        t = torch.from_numpy(a).to(self._comm_device())
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(out, t, group=self.group)
+        return np.stack([o.cpu().numpy() for o in out], axis=0)

@@ -1,0 +1,204 @@
+"""Host-side compilation of the reference's object graph into the POD descriptors of include/mcx.h.
+
+  SimPlan   <- (model, simulation timeline, scheme, num_steps)      drives K1 (engine/engine.py:35-123 in the reference)
+  BookPlan  <- (products, netting sets, exposure grid, metrics)     drives K2/K3/K4 (controller.py:294-471)
+
+Everything here is tiny host work (float-keyed timelines, closed-form coefficients); it must reproduce the reference's
+float arithmetic exactly because later lookups are keyed on these floats (SURVEY.md "float-keyed timelines").
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _abi
+from .common.enums import SimulationScheme
+
+
+class SimPlan:
+    """Sub-step table of MonteCarloEngine's time loop.
+
+    Reference semantics kept (engine/engine.py:46-62): t_prev starts at the calibration date and advances by repeated
+    `+ dt` (never snapped to the timeline date); a timeline date with dt <= 0 (the calibration date itself) is stored
+    without stepping; models see delta_t = (t_prev + dt) - t_prev while the ANALYTICAL Cholesky factor is keyed on dt."""
+
+    def __init__(self, model, timeline, scheme: SimulationScheme, num_steps: int):
+        if not model._supports_scheme(scheme):
+            raise NotImplementedError(f"{type(model).__name__} does not implement the {scheme.name} scheme")
+        self.model, self.scheme, self.num_steps = model, scheme, int(num_steps)
+        self.timeline = np.asarray(timeline, dtype=np.float64).reshape(-1)
+        slots = model._slots()
+        if len(slots) > _abi.MAX_SLOTS:
+            raise ValueError(f"at most {_abi.MAX_SLOTS} sub-models are supported")
+        self.n_slots = len(slots)
+        self.n_state = sum(s.state_dim for s in slots)
+        self.n_z = sum(s.sim_dim for s in slots)
+        if self.n_z > _abi.MAX_Z or self.n_state > _abi.MAX_STATE:
+            raise ValueError("simulation / state dimension exceeds MCX_MAX_Z / MCX_MAX_STATE")
+        self.n_uniform = int(getattr(model, "_n_uniform", lambda s: 0)(scheme))
+        self.n_dates = len(self.timeline)
+
+        steps, aux, chols, chol_key = [], [], [], {}
+        t_prev = np.float64(model.t0())
+        self.n_initial_store = 0
+        for ti, t_now in enumerate(self.timeline):
+            dt = (t_now - t_prev) / np.float64(self.num_steps)
+            if dt > 0:
+                for _ in range(self.num_steps):
+                    t2 = t_prev + dt
+                    dt_model = float(t2 - t_prev)
+                    key = float(dt) if scheme == SimulationScheme.ANALYTICAL else None
+                    if key not in chol_key:
+                        chol_key[key] = len(chols)
+                        chols.append(model.get_cholesky(scheme, float(dt)).detach().cpu().numpy().astype(np.float64))
+                    steps.append((dt_model, math.sqrt(dt_model), float(t_prev), -1, chol_key[key]))
+                    per_slot = model._step_aux(scheme, float(t_prev), dt_model)
+                    row = np.zeros((self.n_slots, _abi.AUX))
+                    for s, vals in enumerate(per_slot):
+                        row[s, :len(vals)] = vals
+                    aux.append(row)
+                    t_prev = t2
+                steps[-1] = steps[-1][:3] + (ti,) + steps[-1][4:]
+            else:
+                if steps:
+                    raise ValueError("non-increasing simulation timeline")
+                self.n_initial_store += 1
+        self.steps = np.array(steps, dtype=_abi.STEP_DTYPE) if steps else np.zeros(0, dtype=_abi.STEP_DTYPE)
+        self.n_steps = len(steps)
+        self.aux = np.ascontiguousarray(np.stack(aux)) if aux else np.zeros((0, self.n_slots, _abi.AUX))
+        self.chol = np.ascontiguousarray(np.stack(chols)) if chols else np.zeros((0, self.n_z, self.n_z))
+        self.init_state = np.array(model._initial_state(), dtype=np.float64)
+        self.flags = _abi.FLAG_SMOOTHING if model.perform_smoothing else 0
+
+        d = _abi.SimDesc()
+        d.scheme, d.n_slots, d.n_state, d.n_z = scheme.value, self.n_slots, self.n_state, self.n_z
+        d.n_uniform, d.n_steps, d.n_dates, d.n_chol = self.n_uniform, self.n_steps, self.n_dates, len(chols)
+        d.n_initial_store, d.flags = self.n_initial_store, self.flags
+        so = zo = 0
+        for i, s in enumerate(slots):
+            d.slots[i].kind, d.slots[i].state_off, d.slots[i].z_off, d.slots[i].flags = s.kind, so, zo, s.flags
+            for j, v in enumerate(s.params):
+                d.slots[i].p[j] = v
+            so += s.state_dim
+            zo += s.sim_dim
+        d.steps, d.chol, d.aux, d.init_state = (_abi.ptr(self.steps), _abi.ptr(self.chol), _abi.ptr(self.aux),
+                                                _abi.ptr(self.init_state))
+        self.desc = d                      # keeps pointers into the numpy arrays above (kept alive by self)
+
+    @property
+    def path_steps_per_path(self) -> int:
+        return self.n_steps
+
+
+class BookCompiler:
+    """Accumulates atoms / terms / events while products and metrics describe themselves."""
+
+    def __init__(self, model, sim_timeline, n_basis: int):
+        self.model = model
+        self.time_to_index = {float(t): i for i, t in enumerate(sim_timeline)}
+        self.n_basis = n_basis
+        self.atoms: list[tuple] = []
+        self._atom_key: dict = {}
+        self.terms: list[tuple] = []
+        self.events: list[tuple] = []
+
+    def tidx(self, time) -> int:
+        return self.time_to_index[float(time)]
+
+    def atom(self, req, asset_id, time) -> int:
+        ti = self.tidx(time)
+        key = (ti, asset_id, req.key())
+        if key not in self._atom_key:
+            co = self.model._atom(req, asset_id)
+            self._atom_key[key] = len(self.atoms)
+            self.atoms.append((ti, -1 if co.col is None else co.col, co.a, co.d, co.b, co.c0, co.c1))
+        return self._atom_key[key]
+
+    def const_atom(self, value: float) -> int:
+        key = ("const", float(value))
+        if key not in self._atom_key:
+            self._atom_key[key] = len(self.atoms)
+            self.atoms.append((0, -1, float(value), 0.0, 0.0, 0.0, 0.0))
+        return self._atom_key[key]
+
+    def add_terms(self, terms) -> tuple[int, int]:
+        b = len(self.terms)
+        for t in terms:
+            self.terms.append((float(t[0]), int(t[1]), int(t[2]) if len(t) > 2 else -1))
+        return b, len(self.terms)
+
+    def add_event(self, kind, t_idx, num_atom, x_atom, term_range, coeff_off, expo_row, strike=0.0, sign=1.0,
+                  aux=(0.0, 0.0, 0.0, 0.0)) -> int:
+        self.events.append((kind, t_idx, num_atom, x_atom, term_range[0], term_range[1], coeff_off, expo_row,
+                            float(strike), float(sign), tuple(aux)))
+        return len(self.events) - 1
+
+
+class BookPlan:
+    """Frozen descriptor arrays + bookkeeping the controller needs (coefficient offsets, atom ids of requests)."""
+
+    def __init__(self, comp: BookCompiler, products: np.ndarray, n_netting_sets: int, n_expo_rows: int, n_coeffs: int,
+                 want_cfs: bool, want_expo: bool, n_state: int):
+        self.atoms = np.array(comp.atoms, dtype=_abi.ATOM_DTYPE) if comp.atoms else np.zeros(0, dtype=_abi.ATOM_DTYPE)
+        self.terms = np.array(comp.terms, dtype=_abi.TERM_DTYPE) if comp.terms else np.zeros(0, dtype=_abi.TERM_DTYPE)
+        self.events = np.array(comp.events, dtype=_abi.EVENT_DTYPE) if comp.events else np.zeros(0, dtype=_abi.EVENT_DTYPE)
+        self.products = products
+        self.coeffs = np.zeros(max(n_coeffs, 1), dtype=np.float64)
+        self.n_netting_sets, self.n_expo_rows, self.n_basis = n_netting_sets, n_expo_rows, comp.n_basis
+        self.n_state = n_state
+        d = _abi.BookDesc()
+        d.n_atoms, d.n_terms, d.n_events, d.n_products = len(self.atoms), len(self.terms), len(self.events), len(products)
+        d.n_netting_sets, d.n_expo_rows, d.n_basis, d.n_coeffs = n_netting_sets, n_expo_rows, comp.n_basis, len(self.coeffs)
+        d.want_cfs, d.want_expo = int(want_cfs), int(want_expo)
+        d.atoms, d.terms, d.events, d.products = (_abi.ptr(self.atoms), _abi.ptr(self.terms), _abi.ptr(self.events),
+                                                  _abi.ptr(self.products))
+        d.coeffs = _abi.ptr(self.coeffs)
+        self.desc = d
+
+
+class UnsecuredSpec:
+    """mcx_unsecured_desc of one netting set (products/netting_set.py:156-184)."""
+
+    def __init__(self, rows, delayed, threshold: float, collateralized: bool):
+        self.rows = np.ascontiguousarray(rows, dtype=np.int32)
+        self.delayed = None if delayed is None else np.ascontiguousarray(delayed, dtype=np.int32)
+        self.n_dates = len(self.rows)
+        d = _abi.UnsecuredDesc()
+        d.n_dates, d.collateralized, d.threshold = self.n_dates, int(collateralized), float(threshold)
+        d.row, d.delayed = _abi.ptr(self.rows), _abi.ptr(self.delayed)
+        self.desc = d
+
+
+def solve_normal_equations(moments: np.ndarray, K: int, S: int, shift: float, scale: float, degenerate: bool,
+                           x0: float) -> np.ndarray:
+    """Least-squares coefficients [S][K] in the RAW monomial basis from the moments of the shifted/scaled basis
+    z = (x - shift) * scale  (what torch.linalg.lstsq(A, Y) returns in the reference, controller.py:370-374).
+
+    degenerate (all paths share x = x0, e.g. the t = calibration-date regression): the reference's gelsy driver
+    returns the minimum-norm solution of the rank-1 system, i.e. c = v * mean(Y) / (v.v) with v = [1, x0, .., x0^(K-1)].
+    """
+    m = np.asarray(moments, dtype=np.float64)
+    n = m[0]
+    out = np.zeros((S, K))
+    if n <= 0:
+        return out
+    if degenerate:
+        v = np.array([x0 ** k for k in range(K)])
+        for s in range(S):
+            mean_y = m[(2 * K - 1) + s * K] / n
+            out[s] = v * (mean_y / float(v @ v))
+        return out
+    G = np.array([[m[j + k] for k in range(K)] for j in range(K)])
+    rhs = np.array([[m[(2 * K - 1) + s * K + k] for k in range(K)] for s in range(S)]).T     # [K][S]
+    try:
+        b = np.linalg.solve(G, rhs)
+    except np.linalg.LinAlgError:
+        b = np.linalg.lstsq(G, rhs, rcond=None)[0]
+    # z^k = scale^k (x - shift)^k  -> expand into monomials of x
+    T = np.zeros((K, K))            # T[j][k] = coefficient of x^j in z^k
+    for k in range(K):
+        for j in range(k + 1):
+            T[j, k] = (scale ** k) * math.comb(k, j) * ((-shift) ** (k - j))
+    return (T @ b).T

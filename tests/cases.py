@@ -1,0 +1,186 @@
+"""The controller cases of tests/golden/gen_golden.py rebuilt with the mcx classes (same constructor arguments)."""
+import os
+
+import numpy as np
+import torch
+
+from mcx.common.enums import SimulationScheme
+from mcx.controller.controller import SimulationController
+from mcx.metrics.ce_metric import CEMetric
+from mcx.metrics.cva_metric import CVAMetric
+from mcx.metrics.eepe_metric import EEPEMetric
+from mcx.metrics.ene_metric import ENEMetric
+from mcx.metrics.epe_metric import EPEMetric
+from mcx.metrics.pfe_metric import PFEMetric
+from mcx.metrics.pv_metric import PVMetric
+from mcx.metrics.risk_metrics import RiskMetrics
+from mcx.models.black_scholes import BlackScholesModel
+from mcx.models.cirpp import CIRPPModel
+from mcx.models.heston import HestonModel
+from mcx.models.model_config import ModelConfig
+from mcx.models.vasicek import VasicekModel
+from mcx.products.bermudan_option import AmericanOption, BermudanOption
+from mcx.products.bond import Bond
+from mcx.products.equity import Equity
+from mcx.products.european_option import EuropeanOption
+from mcx.products.netting_set import NettingSet
+from mcx.products.product import OptionType
+from mcx.products.swap import InterestRateSwap, IRSType
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+A, E, Q = SimulationScheme.ANALYTICAL, SimulationScheme.EULER, SimulationScheme.QE
+
+HAZARDS = {
+    0.5: 0.006402303360855854, 1.0: 0.01553038972325307, 2.0: 0.009729741230773657,
+    3.0: 0.015552544648116201, 4.0: 0.021196186202801115, 5.0: 0.02284319986706472,
+    7.0: 0.010111423894480876, 10.0: 0.00613267811172937, 15.0: 0.0036969930706003337,
+    20.0: 0.003791311459217732,
+}
+
+
+def bs_european():
+    model = BlackScholesModel(0, 120.0, 0.05, 0.2)
+    prod = EuropeanOption(Equity(), 2.0, 100.0, OptionType.CALL)
+    return [NettingSet(name=prod.get_name(), products=[prod])], model, RiskMetrics([PVMetric()])
+
+
+def bs_put_euler():
+    model = BlackScholesModel(0, 90.0, 0.03, 0.35)
+    prod = EuropeanOption(Equity(), 1.5, 100.0, OptionType.PUT)
+    return [NettingSet(name=prod.get_name(), products=[prod])], model, RiskMetrics([PVMetric()])
+
+
+def irs_models(rho, a=0.1, sig=0.01):
+    ir = VasicekModel(0.0, 0.03, 0.05, a, sig, asset_id="irs")
+    cr = CIRPPModel(0.0, "cp", HAZARDS, kappa=0.1, theta=0.01, volatility=0.02, y0=1e-4)
+    return ModelConfig([ir, cr], inter_asset_correlation_matrix=np.array([rho]))
+
+
+def irs_cva():
+    model = irs_models(0.5)
+    irs = InterestRateSwap(0.0, 2.5, 1.0, 0.03, 0.25, 0.25, IRSType.PAYER, "irs")
+    ns = [NettingSet(name=irs.get_name(), products=[irs], counterparty_id="cp")]
+    return ns, model, RiskMetrics([CVAMetric("cp", 0.4)], exposure_timeline=np.arange(11) * 0.25)
+
+
+def irs_cva_linspace():
+    model = irs_models(0.99999, a=0.02, sig=0.2)
+    irs = InterestRateSwap(0.0, 2.0, 1.0, 0.03, 0.25, 0.25, IRSType.PAYER, "irs")
+    ns = [NettingSet(name=irs.get_name(), products=[irs], counterparty_id="cp")]
+    return ns, model, RiskMetrics([CVAMetric("cp", 0.4), PVMetric(), EPEMetric(), ENEMetric()],
+                                  exposure_timeline=np.linspace(0, 2.0, 7))
+
+
+def zcb_cva():
+    ir = VasicekModel(0.0, 0.03, 0.05, 1.0, 0.2, asset_id="bond")
+    cr = CIRPPModel(0.0, "cp", HAZARDS, kappa=0.1, theta=0.01, volatility=0.02, y0=1e-4)
+    model = ModelConfig([ir, cr], inter_asset_correlation_matrix=np.array([0.0]))
+    zb = Bond(0.0, 2.0, 1, 2.0, True, 0.0, "bond")
+    ns = [NettingSet(name=zb.get_name(), products=[zb], counterparty_id="cp")]
+    return ns, model, RiskMetrics([CVAMetric("cp", 0.4)], exposure_timeline=np.linspace(0, 2.0, 9))
+
+
+def heston():
+    model = HestonModel(0, 800.0, 0.04, 0.45545583, -0.78975708, 0.01713417, 2.0, 0.0286834)
+    prod = EuropeanOption(Equity(), 1.0, 720.0, OptionType.CALL)
+    return [NettingSet(name=prod.get_name(), products=[prod])], model, RiskMetrics([PVMetric()])
+
+
+def heston_highpsi():
+    model = HestonModel(0, 100.0, 0.02, 1.2, -0.5, 0.5, 0.02, 0.02)
+    prod = EuropeanOption(Equity(), 1.0, 95.0, OptionType.PUT)
+    return [NettingSet(name=prod.get_name(), products=[prod])], model, RiskMetrics([PVMetric()])
+
+
+def bermudan_swaption():
+    model = VasicekModel(0.0, 0.03, 0.05, 0.1, 0.01)
+    und = InterestRateSwap(0.0, 2.0, 1.0, 0.03, 0.25, 0.25, IRSType.PAYER)
+    prod = BermudanOption(und, [0.125 * k for k in range(1, 16)], 0.0, OptionType.CALL)
+    ns = [NettingSet(name="berm_ns", products=[prod])]
+    tl = np.array([0.125 * k for k in range(0, 17)])
+    mets = [EPEMetric(), PFEMetric(0.95), ENEMetric(), EEPEMetric(), CEMetric(), PVMetric(), PFEMetric(0.5)]
+    return ns, model, RiskMetrics(mets, exposure_timeline=tl)
+
+
+def american():
+    model = BlackScholesModel(0.0, 100.0, 0.05, 0.5)
+    prod = AmericanOption(Equity("id"), 3.0, 12, 100.0, OptionType.PUT)
+    return [NettingSet(name=prod.get_name(), products=[prod])], model, RiskMetrics([PVMetric()])
+
+
+def netting():
+    model = VasicekModel(0.0, 0.02, 0.04, 0.3, 0.015, asset_id="r")
+    irs1 = InterestRateSwap(0.0, 2.0, 1.0, 0.025, 0.5, 0.25, IRSType.PAYER, "r")
+    irs2 = InterestRateSwap(0.0, 1.5, 2.0, 0.035, 0.5, 0.5, IRSType.RECEIVER, "r")
+    bond = Bond(0.0, 2.0, 0.1, 0.5, True, 0.03, "r")
+    frn = Bond(0.0, 1.0, 0.05, 0.25, True, None, "r")
+    ns1 = NettingSet(name="ns_coll", products=[irs1, bond], threshold=0.002, margin_period_of_risk=0.25)
+    ns2 = NettingSet(name="ns_thr", products=[irs2, frn], threshold=0.01)
+    tl = np.array([0.0, 0.25, 0.5, 0.75, 1.0, 1.5, 2.0])
+    mets = [EPEMetric(), ENEMetric(), PFEMetric(0.9), PVMetric(), EEPEMetric(), CEMetric()]
+    return [ns1, ns2], model, RiskMetrics(mets, exposure_timeline=tl)
+
+
+def bond_option():
+    model = VasicekModel(0.0, 0.03, 0.05, 0.2, 0.02, asset_id="r")
+    und_b = Bond(0.0, 3.0, 1.0, 0.5, True, 0.04, "r")
+    und_s = InterestRateSwap(0.0, 3.0, 1.0, 0.035, 0.5, 0.25, IRSType.PAYER, "r")
+    o1 = EuropeanOption(und_b, 1.0, 0.98, OptionType.CALL, asset_id="r")
+    o1.name = "bond_call"
+    o2 = EuropeanOption(und_s, 1.0, 0.0, OptionType.PUT, asset_id="r")
+    o2.name = "swaption_put"
+    return [NettingSet(name="o1", products=[o1]), NettingSet(name="o2", products=[o2])], model, RiskMetrics([PVMetric()])
+
+
+def mixed_cva():
+    eq = BlackScholesModel(0.0, 100.0, 0.03, 0.22, asset_id="equity")
+    ra = VasicekModel(0.0, 0.03, 0.03, 1.0, 0.01, asset_id="rates")
+    cr = CIRPPModel(0.0, "cp", HAZARDS, kappa=0.10, theta=0.01, volatility=0.02, y0=1e-4, deterministic=True)
+    model = ModelConfig([eq, ra, cr], inter_asset_correlation_matrix=[np.array([0.0])] * 3)
+    prods = []
+    o = EuropeanOption(Equity("equity"), 1.0, 95.0, OptionType.CALL, asset_id="equity"); o.name = "call0"; prods.append(o)
+    o = EuropeanOption(Equity("equity"), 2.0, 105.0, OptionType.CALL, asset_id="equity"); o.name = "call1"; prods.append(o)
+    b = Bond(0.0, 2.0, 2.0, 0.5, True, 0.02, "rates"); b.name = "bond0"; prods.append(b)
+    s = InterestRateSwap(0.0, 2.0, 25.0, 0.025, 0.5, 0.25, IRSType.PAYER, "rates"); s.name = "swap0"; prods.append(s)
+    ns = [NettingSet(name="mixed", products=prods, counterparty_id="cp")]
+    return ns, model, RiskMetrics([CVAMetric("cp", 0.4), EPEMetric()], exposure_timeline=np.linspace(0.0, 2.5, 8))
+
+
+# name -> (builder, n_pre, n_main, num_steps, scheme, differentiate)
+CASES = {
+    "bs_european": (bs_european, 0, 2048, 10, A, False),
+    "bs_european_aad": (bs_european, 0, 2048, 10, A, True),
+    "bs_put_euler_aad": (bs_put_euler, 0, 1024, 8, E, True),
+    "irs_cva": (irs_cva, 1024, 1024, 2, E, False),
+    "irs_cva_linspace": (irs_cva_linspace, 1024, 1024, 2, E, False),
+    "zcb_cva": (zcb_cva, 1024, 1024, 2, E, False),
+    "heston_qe": (heston, 0, 1024, 8, Q, False),
+    "heston_qe_aad": (heston, 0, 1024, 8, Q, True),
+    "heston_highpsi_qe": (heston_highpsi, 0, 1024, 6, Q, False),
+    "heston_euler": (heston, 0, 1024, 8, E, False),
+    "bermudan_swaption": (bermudan_swaption, 1024, 1024, 1, E, False),
+    "american_put": (american, 2048, 1024, 1, A, False),
+    "netting": (netting, 1024, 1024, 1, A, False),
+    "bond_option": (bond_option, 0, 1024, 2, A, False),
+    "mixed_cva": (mixed_cva, 512, 512, 2, E, False),
+}
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def make_controller(name, backend, inject=True):
+    build, n_pre, n_main, steps, scheme, diff = CASES[name]
+    ns, model, rm = build()
+    sc = SimulationController(ns, model, rm, n_main, n_pre, steps, scheme, differentiate=diff, backend=backend)
+    g = load_golden(name)
+    if inject:
+        def prep(key_z, key_u):
+            z = backend.from_numpy(np.ascontiguousarray(np.transpose(g[key_z], (0, 2, 1))))      # [S][n_z][N]
+            u = backend.from_numpy(np.ascontiguousarray(g[key_u][:, :, 0])) if key_u in g.files else None
+            return z, u
+        sc._inject["main"] = prep("z_main", "u_main")
+        if "z_pre" in g.files:
+            sc._inject["pre"] = prep("z_pre", "u_pre")
+    return sc, g
