@@ -1,0 +1,166 @@
+// k2_book.hip — K2: fused request resolution + cashflows + exposures (one pass over the paths tensor).
+//
+// Replaces, per path, RequestInterface.resolve_requests (request_interface.py:115-130: ~2.4 GB of materialised [N]
+// vectors at 1 M paths), Product.compute_normalized_cashflows / get_value (bond.py, swap.py, european_option.py,
+// bermudan_option.py) and the exposure evaluation `A @ coeffs / numeraire` of controller.py:385-471, summed per netting
+// set (controller.py:584-591).  Market quantities are "atoms" evaluated in registers from the simulated state; nothing
+// is materialised except the outputs the Metrics API consumes: cfs [NS][N] and exposures [NS][E][N].
+//
+// One lane = one path; the event program (products -> events -> terms) is wave-uniform, so it is walked with scalar
+// loads and scalar branches; all HBM accesses are 512-byte coalesced rows of the [date][state][path] layout.
+#include "mcx_internal.h"
+
+namespace {
+
+struct K2Args {
+    const DevTerm* __restrict__ terms;
+    const DevEvent* __restrict__ events;
+    const DevProduct* __restrict__ products;
+    const DevAtom* __restrict__ atoms;
+    const double* __restrict__ coeffs;
+    const double* __restrict__ paths;
+    double* __restrict__ cfs;
+    double* __restrict__ expo;
+    int64_t n, ld, ld_out;
+    int32_t n_products, n_basis, n_state, n_expo_rows, want_cfs, want_expo;
+};
+
+__device__ __forceinline__ double dev_poly(const double* __restrict__ c, int K, double x)
+{
+    double v = 0.0, xp = 1.0;
+    for (int k = 0; k < K; ++k) { v = fma(c[k], xp, v); xp *= x; }
+    return v;
+}
+
+__device__ __forceinline__ double dev_norm_cdf(double x) { return 0.5 * (1.0 + erf(x * 0.70710678118654752440)); }
+
+// normalised cashflow of one product-date event for a path in exercise state s (s may be decremented)
+__device__ __forceinline__ double dev_cash_event(const DevEvent& e, const DevTerm* __restrict__ terms, const DevAtom* __restrict__ atoms,
+                                                 const double* __restrict__ coeffs, int K, const double* __restrict__ paths,
+                                                 int64_t D, int64_t ld, int64_t i, int& s)
+{
+    const double num = dev_atom(e.num, paths, D, ld, i);
+    double common = 0.0, own = 0.0;
+    for (int j = e.term_begin; j < e.term_end; ++j) {
+        const double v = terms[j].w * dev_atom(terms[j].atom, paths, D, ld, i);
+        if (terms[j].den < 0) common += v;
+        else own += v / dev_atom(atoms[terms[j].den], paths, D, ld, i);
+    }
+    if (e.kind == MCX_EV_CASHFLOW) return common / num + own;
+    const double imm = fmax(e.sign * (common - e.strike), 0.0);
+    if (e.kind == MCX_EV_OPTION) return imm / num;
+    double cont = 0.0;                                        // MCX_EV_EXERCISE (bermudan_option.py:93-131)
+    if (e.coeff_off >= 0) cont = dev_poly(coeffs + e.coeff_off + s * K, K, dev_atom(e.x, paths, D, ld, i));
+    const bool ex = (imm > cont) && (s > 0);
+    if (ex) s -= 1;
+    return ex ? imm / num : 0.0;
+}
+
+__global__ __launch_bounds__(MCX_BLOCK) void k2_eval_book(const K2Args a)
+{
+    const int64_t i = (int64_t)blockIdx.x * MCX_BLOCK + threadIdx.x;
+    if (i >= a.n) return;
+    const int64_t D = a.n_state, ld = a.ld;
+    const int K = a.n_basis;
+    int cur_ns = -1;
+    double acc_ns = 0.0;
+    for (int p = 0; p < a.n_products; ++p) {
+        const DevProduct pr = a.products[p];
+        if (pr.ev_end == pr.ev_begin) continue;              // analytically valued product: no Monte-Carlo events
+        if (pr.netting_set != cur_ns) {
+            if (cur_ns >= 0 && a.want_cfs) a.cfs[(int64_t)cur_ns * a.ld_out + i] = acc_ns;
+            cur_ns = pr.netting_set;
+            acc_ns = 0.0;
+        }
+        int s = pr.init_state;
+        double acc = 0.0;
+        for (int q = pr.ev_begin; q < pr.ev_end; ++q) {
+            const DevEvent& e = a.events[q];
+            if (e.kind <= MCX_EV_EXERCISE) {
+                acc += dev_cash_event(e, a.terms, a.atoms, a.coeffs, K, a.paths, D, ld, i, s);
+            } else {
+                double v = 0.0;
+                if (e.kind == MCX_EV_EXPO_POLY) {
+                    const double num = dev_atom(e.num, a.paths, D, ld, i);
+                    const double x = dev_atom(e.x, a.paths, D, ld, i);
+                    const double cont = e.coeff_off >= 0 ? dev_poly(a.coeffs + e.coeff_off + s * K, K, x) : 0.0;
+                    v = cont / num;
+                } else if (e.aux[2] > 0.0) {                  // MCX_EV_EXPO_BS (european_option.py:88-145)
+                    const double num = dev_atom(e.num, a.paths, D, ld, i);
+                    const double spot = dev_atom(e.x, a.paths, D, ld, i);
+                    const double sig = e.aux[0], rate = e.aux[1], tau = e.aux[2], Kx = e.strike;
+                    const double sq = sqrt(tau);
+                    const double d1 = (log(spot / Kx) + (rate + 0.5 * sig * sig) * tau) / (sig * sq);
+                    const double d2 = d1 - sig * sq;
+                    const double df = exp(-rate * tau);
+                    const double price = e.sign > 0.0 ? spot * dev_norm_cdf(d1) - Kx * df * dev_norm_cdf(d2)
+                                                      : Kx * df * dev_norm_cdf(-d2) - spot * dev_norm_cdf(-d1);
+                    v = price / num;
+                }
+                double* dst = a.expo + ((int64_t)pr.netting_set * a.n_expo_rows + e.row) * a.ld_out + i;
+                if (e.flags & 1) *dst += v;
+                else *dst = v;
+            }
+        }
+        acc_ns += acc;
+    }
+    if (cur_ns >= 0 && a.want_cfs) a.cfs[(int64_t)cur_ns * a.ld_out + i] = acc_ns;
+}
+
+__global__ __launch_bounds__(MCX_BLOCK) void k2_resolve(const DevAtom* __restrict__ atoms, const int32_t* __restrict__ ids, int n_ids,
+                                                        const double* __restrict__ paths, int64_t D, int64_t n, int64_t ld,
+                                                        double* __restrict__ out, int64_t ld_out)
+{
+    const int64_t i = (int64_t)blockIdx.x * MCX_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int q = blockIdx.y;
+    out[(int64_t)q * ld_out + i] = dev_atom(atoms[ids[q]], paths, D, ld, i);
+}
+
+}  // namespace
+
+extern "C" int mcx_eval_book(mcx_handle* h, const mcx_book* b, const double* d_paths, int64_t n_paths, int64_t ld,
+                             double* d_cfs, double* d_expo, int64_t ld_out, void* stream)
+{
+    if (!h || !b || !d_paths) return -1;
+    if (n_paths <= 0) return 0;
+    if (ld < n_paths || ld_out < n_paths) MCX_FAIL(h, -2, "mcx_eval_book: leading dimension < n_paths");
+    if (b->want_cfs && !d_cfs) MCX_FAIL(h, -2, "mcx_eval_book: d_cfs is NULL but cashflows are required");
+    if (b->want_expo && !d_expo) MCX_FAIL(h, -2, "mcx_eval_book: d_expo is NULL but exposures are required");
+    hipStream_t s = (hipStream_t)stream;
+    // netting sets without a Monte-Carlo product keep zero cashflows; exposure rows nobody writes are zeroed
+    if (b->want_cfs) MCX_HIP(h, hipMemsetAsync(d_cfs, 0, sizeof(double) * (size_t)b->n_netting_sets * ld_out, s));
+    if (b->want_expo && b->expo_needs_memset)
+        MCX_HIP(h, hipMemsetAsync(d_expo, 0, sizeof(double) * (size_t)b->n_netting_sets * b->n_expo_rows * ld_out, s));
+    K2Args a;
+    a.terms = b->d_terms; a.events = b->d_events; a.products = b->d_products; a.atoms = b->d_atoms; a.coeffs = b->d_coeffs;
+    a.paths = d_paths; a.cfs = d_cfs; a.expo = d_expo; a.n = n_paths; a.ld = ld; a.ld_out = ld_out;
+    a.n_products = b->n_products; a.n_basis = b->n_basis; a.n_state = b->n_state; a.n_expo_rows = b->n_expo_rows;
+    a.want_cfs = b->want_cfs; a.want_expo = b->want_expo;
+    const int grid = (int)((n_paths + MCX_BLOCK - 1) / MCX_BLOCK);
+    hipLaunchKernelGGL(k2_eval_book, dim3(grid), dim3(MCX_BLOCK), 0, s, a);
+    MCX_HIP(h, hipGetLastError());
+    return 0;
+}
+
+extern "C" int mcx_resolve_atoms(mcx_handle* h, const mcx_book* b, const int32_t* h_atom_ids, int32_t n_ids, const double* d_paths,
+                                 int64_t n_paths, int64_t ld, double* d_out, int64_t ld_out, void* stream)
+{
+    if (!h || !b || !h_atom_ids || !d_paths || !d_out) return -1;
+    if (n_ids <= 0 || n_paths <= 0) return 0;
+    if (n_ids > 65535) MCX_FAIL(h, -2, "mcx_resolve_atoms: too many atoms in one call");
+    for (int q = 0; q < n_ids; ++q)
+        if (h_atom_ids[q] < 0 || h_atom_ids[q] >= b->n_atoms) MCX_FAIL(h, -2, "mcx_resolve_atoms: atom id out of range");
+    hipStream_t s = (hipStream_t)stream;
+    int32_t* d_ids = nullptr;
+    MCX_HIP(h, hipMalloc(&d_ids, sizeof(int32_t) * (size_t)n_ids));
+    MCX_HIP(h, hipMemcpyAsync(d_ids, h_atom_ids, sizeof(int32_t) * (size_t)n_ids, hipMemcpyHostToDevice, s));
+    MCX_HIP(h, hipStreamSynchronize(s));
+    const int gx = (int)((n_paths + MCX_BLOCK - 1) / MCX_BLOCK);
+    hipLaunchKernelGGL(k2_resolve, dim3(gx, n_ids), dim3(MCX_BLOCK), 0, s, b->d_atoms, d_ids, n_ids, d_paths, (int64_t)b->n_state,
+                       n_paths, ld, d_out, ld_out);
+    MCX_HIP(h, hipGetLastError());
+    MCX_HIP(h, hipStreamSynchronize(s));
+    MCX_HIP(h, hipFree(d_ids));
+    return 0;
+}

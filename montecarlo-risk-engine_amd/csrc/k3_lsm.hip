@@ -1,0 +1,311 @@
+// k3_lsm.hip — K3: Longstaff-Schwartz pre-simulation step.
+//
+// Replaces one iteration of the reference's backward loop (controller/controller.py:316-383): roll the cached future
+// cashflows one window back along the exercise policy (cf_cache, :325-352), multiply by the numeraire at the regression
+// date (:368) and form the normal equations of the monomial regression that torch.linalg.lstsq solves (:370-374).
+// The K x K solve (K <= 6) happens on the host after the cross-GPU all-reduce of the moments.
+//
+// Two moment kernels:
+//   * VALU + wave64 shuffle reduction (default): each lane keeps the 2K-1 + S*K running sums of its paths in VGPRs;
+//   * MFMA (MCX_LSM_MFMA): the Gram matrix of the feature rows f = [1, z, .., z^(K-1), Y_0 .. Y_(S-1)] is accumulated with
+//     v_mfma_f64_16x16x4_f64 — A = F^T (16 features x 4 paths), B = F (4 paths x 16 features) per instruction; the
+//     features of 64 paths are staged through LDS in a bank-conflict-free [feature][path] image (row stride 66 doubles).
+// Both read each path's state once (HBM-bound: 8*(1+S+atoms) B/path).
+#include "mcx_internal.h"
+
+namespace {
+
+struct K3Args {
+    const DevTerm* __restrict__ terms;
+    const DevEvent* __restrict__ events;   // already offset to the product's cf_begin
+    const DevAtom* __restrict__ atoms;
+    const double* __restrict__ coeffs;
+    const double* __restrict__ paths;
+    double* __restrict__ W;
+    double* __restrict__ partials;         // [gridDim.x][NM]
+    DevAtom num, x;
+    double shift, scale;
+    int64_t n, ld, ld_w;
+    int32_t roll_begin, roll_end, n_basis, n_state, f32_cache;
+};
+
+__device__ __forceinline__ double k3_poly(const double* __restrict__ c, int K, double x)
+{
+    double v = 0.0, xp = 1.0;
+    for (int k = 0; k < K; ++k) { v = fma(c[k], xp, v); xp *= x; }
+    return v;
+}
+
+__device__ __forceinline__ double k3_cash_event(const DevEvent& e, const K3Args& a, int64_t D, int64_t i, int& s)
+{
+    const double num = dev_atom(e.num, a.paths, D, a.ld, i);
+    double common = 0.0, own = 0.0;
+    for (int j = e.term_begin; j < e.term_end; ++j) {
+        const double v = a.terms[j].w * dev_atom(a.terms[j].atom, a.paths, D, a.ld, i);
+        if (a.terms[j].den < 0) common += v;
+        else own += v / dev_atom(a.atoms[a.terms[j].den], a.paths, D, a.ld, i);
+    }
+    if (e.kind == MCX_EV_CASHFLOW) return common / num + own;
+    const double imm = fmax(e.sign * (common - e.strike), 0.0);
+    if (e.kind == MCX_EV_OPTION) return imm / num;
+    double cont = 0.0;
+    if (e.coeff_off >= 0) cont = k3_poly(a.coeffs + e.coeff_off + s * a.n_basis, a.n_basis, dev_atom(e.x, a.paths, D, a.ld, i));
+    const bool ex = (imm > cont) && (s > 0);
+    if (ex) s -= 1;
+    return ex ? imm / num : 0.0;
+}
+
+// roll the window for path i; returns Y_s = numeraire * W[s] in y[] and z
+template <int S>
+__device__ __forceinline__ void k3_roll(const K3Args& a, int64_t i, double (&y)[S], double& z)
+{
+    const int64_t D = a.n_state;
+    double w[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) w[s] = a.W[(int64_t)s * a.ld_w + i];
+    if (a.roll_end > a.roll_begin) {
+        double wn[S];
+#pragma unroll
+        for (int s0 = 0; s0 < S; ++s0) {
+            int s = s0;
+            double step_value = 0.0;
+            for (int q = a.roll_begin; q < a.roll_end; ++q) {               // controller.py:333-341
+                step_value += k3_cash_event(a.events[q], a, D, i, s);
+                if (a.f32_cache) step_value = (double)(float)step_value;     // float32 cf_cache quirk (controller.py:312-330)
+            }
+            double tail = w[0];
+#pragma unroll
+            for (int q = 1; q < S; ++q) tail = (s == q) ? w[q] : tail;       // lookup_state_values (product.py:150-155)
+            const double total = step_value + tail;
+            wn[s0] = a.f32_cache ? (double)(float)total : total;
+        }
+#pragma unroll
+        for (int s = 0; s < S; ++s) { w[s] = wn[s]; a.W[(int64_t)s * a.ld_w + i] = wn[s]; }
+    }
+    const double num = dev_atom(a.num, a.paths, D, a.ld, i);
+    const double x = dev_atom(a.x, a.paths, D, a.ld, i);
+    z = (x - a.shift) * a.scale;
+#pragma unroll
+    for (int s = 0; s < S; ++s) y[s] = num * w[s];
+}
+
+template <int K, int S>
+__global__ __launch_bounds__(MCX_BLOCK) void k3_step_valu(const K3Args a)
+{
+    constexpr int NM = (2 * K - 1) + S * K;
+    double acc[NM];
+#pragma unroll
+    for (int q = 0; q < NM; ++q) acc[q] = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * MCX_BLOCK + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * MCX_BLOCK) {
+        double y[S], z;
+        k3_roll<S>(a, i, y, z);
+        double zp = 1.0;
+#pragma unroll
+        for (int k = 0; k < 2 * K - 1; ++k) {
+            acc[k] += zp;
+            if (k < K) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) acc[(2 * K - 1) + s * K + k] = fma(zp, y[s], acc[(2 * K - 1) + s * K + k]);
+            }
+            zp *= z;
+        }
+    }
+    __shared__ double lds[4];
+#pragma unroll
+    for (int q = 0; q < NM; ++q) {
+        const double r = block_sum(acc[q], lds);
+        if (threadIdx.x == 0) a.partials[(int64_t)blockIdx.x * NM + q] = r;
+    }
+}
+
+// ---- MFMA variant ----------------------------------------------------------------------------------------------------
+typedef double double4_t __attribute__((ext_vector_type(4)));
+#define K3_FROW 66   // LDS row stride (doubles) of the [feature][path] image: 2*feature mod 32 spreads the 16 rows over banks
+
+template <int K, int S>
+__global__ __launch_bounds__(MCX_BLOCK) void k3_step_mfma(const K3Args a)
+{
+    constexpr int NF = K + S;                  // features per path (<= 16)
+    constexpr int NM = (2 * K - 1) + S * K;
+    __shared__ double feat[4][16 * K3_FROW];   // one image per wave
+    __shared__ double gram[4][256];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double* img = feat[wv];
+    // zero the padding rows once (features NF..15 stay 0 for the whole kernel)
+    for (int r = NF; r < 16; ++r) img[r * K3_FROW + lane] = 0.0;
+    double4_t accm = {0.0, 0.0, 0.0, 0.0};
+    const int fi = lane & 15, pk = lane >> 4;
+    const int64_t stride = (int64_t)gridDim.x * MCX_BLOCK;
+    // every wave runs the same number of iterations (EXEC must be all ones around the MFMA)
+    const int64_t iters = (a.n + stride - 1) / stride;
+    for (int64_t it = 0; it < iters; ++it) {
+        const int64_t i = it * stride + (int64_t)blockIdx.x * MCX_BLOCK + threadIdx.x;
+        double y[S], z = 0.0;
+        const bool live = i < a.n;
+#pragma unroll
+        for (int s = 0; s < S; ++s) y[s] = 0.0;
+        if (live) k3_roll<S>(a, i, y, z);
+        double zp = live ? 1.0 : 0.0;           // dead lanes contribute an all-zero feature row
+#pragma unroll
+        for (int k = 0; k < K; ++k) { img[k * K3_FROW + lane] = zp; zp *= z; }
+#pragma unroll
+        for (int s = 0; s < S; ++s) img[(K + s) * K3_FROW + lane] = y[s];
+        __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0): this wave's LDS writes have landed (same-wave RAW)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const double v = img[fi * K3_FROW + 4 * g + pk];   // A[i=fi][k=pk] and B[k=pk][j=fi] are the same number
+            accm = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, accm, 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // D[row = 4*(lane/16) + r][col = lane%16] = accm[r]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) gram[wv][(4 * pk + r) * 16 + fi] = accm[r];
+    __syncthreads();
+    if (threadIdx.x < NM) {
+        const int q = threadIdx.x;
+        int row, col;
+        if (q < 2 * K - 1) { row = q < K ? 0 : q - (K - 1); col = q < K ? q : K - 1; }     // sum z^q = G[row][col], row+col = q
+        else { const int s = (q - (2 * K - 1)) / K, k = (q - (2 * K - 1)) % K; row = k; col = K + s; }
+        double r = 0.0;
+        for (int w = 0; w < 4; ++w) r += gram[w][row * 16 + col];
+        a.partials[(int64_t)blockIdx.x * NM + q] = r;
+    }
+}
+
+__global__ void k3_finish(const double* __restrict__ partials, int nm, int n_blocks, double* __restrict__ out)
+{
+    const int q = blockIdx.x;
+    __shared__ double lds[4];
+    double s = 0.0;
+    for (int b = threadIdx.x; b < n_blocks; b += blockDim.x) s += partials[(int64_t)b * nm + q];
+    s = block_sum(s, lds);
+    if (threadIdx.x == 0) out[q] = s;
+}
+
+__global__ __launch_bounds__(MCX_BLOCK) void k3_minmax(const DevAtom* __restrict__ atoms, const int32_t* __restrict__ ids,
+                                                       const double* __restrict__ paths, int64_t D, int64_t n, int64_t ld,
+                                                       double* __restrict__ partials)
+{
+    const int q = blockIdx.y;
+    const DevAtom at = atoms[ids[q]];
+    double lo = INFINITY, hi = -INFINITY;
+    for (int64_t i = (int64_t)blockIdx.x * MCX_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * MCX_BLOCK) {
+        const double x = dev_atom(at, paths, D, ld, i);
+        lo = fmin(lo, x); hi = fmax(hi, x);
+    }
+    lo = wave_min(lo); hi = wave_max(hi);
+    __shared__ double l[4], u[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { l[w] = lo; u[w] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k) { lo = fmin(lo, l[k]); hi = fmax(hi, u[k]); }
+        partials[((int64_t)q * gridDim.x + blockIdx.x) * 2 + 0] = lo;
+        partials[((int64_t)q * gridDim.x + blockIdx.x) * 2 + 1] = hi;
+    }
+}
+
+__global__ void k3_minmax_finish(const double* __restrict__ partials, int n_blocks, double* __restrict__ out)
+{
+    const int q = blockIdx.x;
+    double lo = INFINITY, hi = -INFINITY;
+    for (int b = threadIdx.x; b < n_blocks; b += blockDim.x) {
+        lo = fmin(lo, partials[((int64_t)q * n_blocks + b) * 2 + 0]);
+        hi = fmax(hi, partials[((int64_t)q * n_blocks + b) * 2 + 1]);
+    }
+    lo = wave_min(lo); hi = wave_max(hi);
+    if (threadIdx.x == 0) { out[2 * q] = lo; out[2 * q + 1] = hi; }
+}
+
+template <int K, int S>
+void launch_k3(const K3Args& a, int grid, bool mfma, hipStream_t s)
+{
+    if (mfma) hipLaunchKernelGGL((k3_step_mfma<K, S>), dim3(grid), dim3(MCX_BLOCK), 0, s, a);
+    else hipLaunchKernelGGL((k3_step_valu<K, S>), dim3(grid), dim3(MCX_BLOCK), 0, s, a);
+}
+
+template <int S>
+int dispatch_k3(int K, const K3Args& a, int grid, bool mfma, hipStream_t s)
+{
+    switch (K) {
+    case 1: launch_k3<1, S>(a, grid, mfma, s); return 0;
+    case 2: launch_k3<2, S>(a, grid, mfma, s); return 0;
+    case 3: launch_k3<3, S>(a, grid, mfma, s); return 0;
+    case 4: launch_k3<4, S>(a, grid, mfma, s); return 0;
+    case 5: launch_k3<5, S>(a, grid, mfma, s); return 0;
+    case 6: launch_k3<6, S>(a, grid, mfma, s); return 0;
+    default: return -1;
+    }
+}
+
+}  // namespace
+
+extern "C" int mcx_lsm_stats(mcx_handle* h, const mcx_book* b, const int32_t* h_atom_ids, int32_t n_ids, const double* d_paths,
+                             int64_t n_paths, int64_t ld, double* h_out, void* stream)
+{
+    if (!h || !b || !h_atom_ids || !d_paths || !h_out) return -1;
+    if (n_ids <= 0) return 0;
+    for (int q = 0; q < n_ids; ++q)
+        if (h_atom_ids[q] < 0 || h_atom_ids[q] >= b->n_atoms) MCX_FAIL(h, -2, "mcx_lsm_stats: atom id out of range");
+    if (n_paths <= 0) { for (int q = 0; q < n_ids; ++q) { h_out[2 * q] = INFINITY; h_out[2 * q + 1] = -INFINITY; } return 0; }
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = mcx_grid_for(n_paths, MCX_BLOCK, 256);
+    if ((size_t)n_ids * grid * 2 * sizeof(double) + (size_t)n_ids * 2 * sizeof(double) > h->ws_bytes || n_ids > 65535 ||
+        (size_t)n_ids * 2 * sizeof(double) > h->pinned_bytes)
+        MCX_FAIL(h, -2, "mcx_lsm_stats: too many atoms in one call");
+    int32_t* d_ids = nullptr;
+    MCX_HIP(h, hipMalloc(&d_ids, sizeof(int32_t) * (size_t)n_ids));
+    MCX_HIP(h, hipMemcpyAsync(d_ids, h_atom_ids, sizeof(int32_t) * (size_t)n_ids, hipMemcpyHostToDevice, s));
+    MCX_HIP(h, hipStreamSynchronize(s));
+    double* part = h->d_ws;
+    double* d_out = h->d_ws + (size_t)n_ids * grid * 2;
+    hipLaunchKernelGGL(k3_minmax, dim3(grid, n_ids), dim3(MCX_BLOCK), 0, s, b->d_atoms, d_ids, d_paths, (int64_t)b->n_state, n_paths, ld, part);
+    hipLaunchKernelGGL(k3_minmax_finish, dim3(n_ids), dim3(MCX_WAVE), 0, s, part, grid, d_out);
+    MCX_HIP(h, hipGetLastError());
+    MCX_HIP(h, hipMemcpyAsync(h->h_pinned, d_out, sizeof(double) * 2 * (size_t)n_ids, hipMemcpyDeviceToHost, s));
+    MCX_HIP(h, hipStreamSynchronize(s));
+    memcpy(h_out, h->h_pinned, sizeof(double) * 2 * (size_t)n_ids);
+    MCX_HIP(h, hipFree(d_ids));
+    return 0;
+}
+
+extern "C" int mcx_lsm_step(mcx_handle* h, const mcx_book* b, int32_t product, int32_t roll_begin, int32_t roll_end, int32_t num_atom,
+                            int32_t x_atom, double shift, double scale, const double* d_paths, int64_t n_paths, int64_t ld,
+                            double* d_W, int64_t ld_w, double* d_moments, int32_t flags, void* stream)
+{
+    if (!h || !b || !d_paths || !d_W || !d_moments) return -1;
+    if (product < 0 || product >= b->n_products) MCX_FAIL(h, -2, "mcx_lsm_step: product out of range");
+    const DevProduct& pr = b->h_products[product];
+    const int n_cf = pr.cf_end - pr.cf_begin;
+    if (roll_begin < 0 || roll_end < roll_begin || roll_end > n_cf) MCX_FAIL(h, -2, "mcx_lsm_step: roll window out of range");
+    if (num_atom < 0 || num_atom >= b->n_atoms || x_atom < 0 || x_atom >= b->n_atoms) MCX_FAIL(h, -2, "mcx_lsm_step: atom out of range");
+    if (ld < n_paths || ld_w < n_paths) MCX_FAIL(h, -2, "mcx_lsm_step: leading dimension < n_paths");
+    const int K = b->n_basis, S = pr.n_states;
+    const int NM = (2 * K - 1) + S * K;
+    hipStream_t s = (hipStream_t)stream;
+    if (n_paths <= 0) { MCX_HIP(h, hipMemsetAsync(d_moments, 0, sizeof(double) * NM, s)); return 0; }
+    const int grid = mcx_grid_for(n_paths, MCX_BLOCK, 4 * h->n_cu);
+    if ((size_t)grid * NM * sizeof(double) > h->ws_bytes) MCX_FAIL(h, -2, "mcx_lsm_step: workspace too small");
+    auto flat = [&](int id) { DevAtom o; const mcx_atom& q = b->h_atoms[id]; o.t_idx = q.t_idx; o.col = q.col; o.a = q.a; o.d = q.d; o.b = q.b; o.c0 = q.c0; o.c1 = q.c1; return o; };
+    K3Args a;
+    a.terms = b->d_terms; a.events = b->d_events + pr.cf_begin; a.atoms = b->d_atoms; a.coeffs = b->d_coeffs; a.paths = d_paths;
+    a.W = d_W; a.partials = h->d_ws; a.num = flat(num_atom); a.x = flat(x_atom); a.shift = shift; a.scale = scale;
+    a.n = n_paths; a.ld = ld; a.ld_w = ld_w; a.roll_begin = roll_begin; a.roll_end = roll_end; a.n_basis = K; a.n_state = b->n_state;
+    a.f32_cache = (flags & MCX_LSM_F32_CACHE) ? 1 : 0;
+    const bool mfma = (flags & MCX_LSM_MFMA) != 0;
+    int rc = -1;
+    switch (S) {
+    case 1: rc = dispatch_k3<1>(K, a, grid, mfma, s); break;
+    case 2: rc = dispatch_k3<2>(K, a, grid, mfma, s); break;
+    case 3: rc = dispatch_k3<3>(K, a, grid, mfma, s); break;
+    case 4: rc = dispatch_k3<4>(K, a, grid, mfma, s); break;
+    default: break;
+    }
+    if (rc != 0) MCX_FAIL(h, -3, "mcx_lsm_step: unsupported (basis=%d, states=%d)", K, S);
+    MCX_HIP(h, hipGetLastError());
+    hipLaunchKernelGGL(k3_finish, dim3(NM), dim3(MCX_BLOCK), 0, s, h->d_ws, NM, grid, d_moments);
+    MCX_HIP(h, hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,77 @@
+// k5_select.hip — K5: one digit pass of an exact radix select (PFE without sorting).
+//
+// The reference sorts all N exposures per date (`torch.sort`, metrics/pfe_metric.py:61-66) to read x_(ceil(qN)-1) and its
+// two neighbours.  Here each pass histograms one digit of the order-preserving uint64 image of the doubles; the host
+// walks the digits (6 passes of 11/11/11/11/11/9 bits), narrowing up to three rank prefixes per date at once.  Histograms
+// are integer counters: exact, order-independent and all-reducible across GPUs (no path data leaves a GPU).
+//
+// Per block: an LDS histogram [n_sel][2^bits] of u32 (<= 24 KB), wave-coalesced 512-B row reads, LDS integer atomics,
+// then one global u64 atomic per non-empty bin.
+#include "mcx_internal.h"
+
+namespace {
+
+__device__ __forceinline__ uint64_t dev_key(double x)
+{
+    const uint64_t b = (uint64_t)__double_as_longlong(x);
+    return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+}
+
+#define K5_MAX_SEL 4
+struct K5Prefix { uint64_t p[K5_MAX_SEL]; };
+
+__global__ __launch_bounds__(MCX_BLOCK) void k5_hist(const DevUnsec u, const double* __restrict__ expo, int64_t n, int64_t ld,
+                                                     int n_sel, const uint64_t* __restrict__ prefix, int shift, int bits,
+                                                     unsigned long long* __restrict__ hist)
+{
+    extern __shared__ uint32_t lh[];                  // [n_sel][1<<bits]
+    const int m = blockIdx.y;
+    const int nb = 1 << bits;
+    for (int q = threadIdx.x; q < n_sel * nb; q += MCX_BLOCK) lh[q] = 0;
+    K5Prefix pf;
+    for (int j = 0; j < K5_MAX_SEL; ++j) pf.p[j] = j < n_sel ? prefix[m * n_sel + j] : 0;
+    __syncthreads();
+    const int hi = shift + bits;
+    for (int64_t i = (int64_t)blockIdx.x * MCX_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * MCX_BLOCK) {
+        const uint64_t k = dev_key(dev_unsec(u, expo, ld, m, i));
+        const uint32_t digit = (uint32_t)((k >> shift) & (uint64_t)(nb - 1));
+        for (int j = 0; j < n_sel; ++j) {
+            const bool match = hi >= 64 || (k >> hi) == (pf.p[j] >> hi);
+            if (match) atomicAdd(&lh[j * nb + digit], 1u);
+        }
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < n_sel * nb; q += MCX_BLOCK) {
+        const uint32_t c = lh[q];
+        if (c) atomicAdd(&hist[(int64_t)m * n_sel * nb + q], (unsigned long long)c);
+    }
+}
+
+}  // namespace
+
+extern "C" int mcx_select_hist(mcx_handle* h, const mcx_unsecured_desc* u, const double* d_expo_ns, int64_t n_paths, int64_t ld,
+                               int32_t n_sel, const uint64_t* h_prefix, int32_t shift, int32_t bits, uint64_t* d_hist, void* stream)
+{
+    if (!h || !u || !d_expo_ns || !h_prefix || !d_hist) return -1;
+    if (n_sel < 1 || n_sel > K5_MAX_SEL || bits < 1 || bits > 11 || shift < 0 || shift + bits > 64)
+        MCX_FAIL(h, -2, "mcx_select_hist: bad selection geometry (n_sel=%d shift=%d bits=%d)", n_sel, shift, bits);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t nh = (size_t)u->n_dates * n_sel * ((size_t)1 << bits);
+    MCX_HIP(h, hipMemsetAsync(d_hist, 0, nh * sizeof(uint64_t), s));
+    if (n_paths <= 0) return 0;
+    DevUnsec du; int32_t* tmp = nullptr;
+    int rc = mcx_upload_unsec(h, u, &du, &tmp, s);
+    if (rc) return rc;
+    uint64_t* d_prefix = nullptr;
+    MCX_HIP(h, hipMalloc(&d_prefix, sizeof(uint64_t) * (size_t)u->n_dates * n_sel));
+    MCX_HIP(h, hipMemcpyAsync(d_prefix, h_prefix, sizeof(uint64_t) * (size_t)u->n_dates * n_sel, hipMemcpyHostToDevice, s));
+    MCX_HIP(h, hipStreamSynchronize(s));
+    int gx = mcx_grid_for(n_paths, MCX_BLOCK * 8, 4 * h->n_cu / (u->n_dates > 4 ? 4 : u->n_dates) + 1);
+    const size_t lds = sizeof(uint32_t) * (size_t)n_sel * ((size_t)1 << bits);
+    hipLaunchKernelGGL(k5_hist, dim3(gx, u->n_dates), dim3(MCX_BLOCK), lds, s, du, d_expo_ns, n_paths, ld, (int)n_sel, d_prefix,
+                       (int)shift, (int)bits, (unsigned long long*)d_hist);
+    MCX_HIP(h, hipGetLastError());
+    MCX_HIP(h, hipStreamSynchronize(s));
+    hipFree(d_prefix); hipFree(tmp);
+    return 0;
+}

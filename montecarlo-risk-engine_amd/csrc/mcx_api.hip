@@ -1,0 +1,235 @@
+// mcx_api.hip — handle, book (descriptor flattening + upload) and small shared host helpers of libmcx_hip.so.
+#include "mcx_internal.h"
+
+extern "C" int mcx_abi_version(void) { return MCX_ABI_VERSION; }
+
+extern "C" int mcx_create(mcx_handle** out, int device_id)
+{
+    if (!out) return -1;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) return -2;
+    if (hipSetDevice(device_id) != hipSuccess) return -3;
+    mcx_handle* h = new mcx_handle();
+    h->device = device_id;
+    if (hipGetDeviceProperties(&h->prop, device_id) != hipSuccess) { delete h; return -4; }
+    h->n_cu = h->prop.multiProcessorCount;
+    h->ws_bytes = 8u << 20;
+    h->pinned_bytes = 1u << 20;
+    h->d_ws = nullptr;
+    h->h_pinned = nullptr;
+    if (hipMalloc(&h->d_ws, h->ws_bytes) != hipSuccess) { delete h; return -5; }
+    if (hipHostMalloc(&h->h_pinned, h->pinned_bytes, hipHostMallocDefault) != hipSuccess) { hipFree(h->d_ws); delete h; return -6; }
+    *out = h;
+    return 0;
+}
+
+extern "C" void mcx_destroy(mcx_handle* h)
+{
+    if (!h) return;
+    hipFree(h->d_ws);
+    hipHostFree(h->h_pinned);
+    delete h;
+}
+
+extern "C" const char* mcx_last_error(mcx_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+extern "C" int mcx_device_info(mcx_handle* h, int32_t* n_cu, int64_t* hbm_bytes, char* name, int32_t name_len)
+{
+    if (!h) return -1;
+    if (n_cu) *n_cu = h->n_cu;
+    if (hbm_bytes) *hbm_bytes = (int64_t)h->prop.totalGlobalMem;
+    if (name && name_len > 0) snprintf(name, (size_t)name_len, "%s (%s)", h->prop.name, h->prop.gcnArchName);
+    return 0;
+}
+
+// ---- book ------------------------------------------------------------------------------------------------------------
+static DevAtom flat_atom(const mcx_atom& a)
+{
+    DevAtom o;
+    o.t_idx = a.t_idx; o.col = a.col; o.a = a.a; o.d = a.d; o.b = a.b; o.c0 = a.c0; o.c1 = a.c1;
+    return o;
+}
+
+extern "C" int mcx_book_create(mcx_handle* h, const mcx_book_desc* d, mcx_book** out)
+{
+    if (!h || !d || !out) return -1;
+    if (d->n_basis < 1 || d->n_basis > MCX_MAX_BASIS) MCX_FAIL(h, -2, "mcx_book_create: n_basis %d out of range", d->n_basis);
+    if (d->n_state < 1 || d->n_state > MCX_MAX_STATE) MCX_FAIL(h, -2, "mcx_book_create: n_state %d out of range", d->n_state);
+    // validate every index the kernels will dereference (a wild index on the GPU can take the whole node down)
+    for (int i = 0; i < d->n_atoms; ++i)
+        if (d->atoms[i].col >= d->n_state || d->atoms[i].t_idx < 0) MCX_FAIL(h, -3, "mcx_book_create: atom %d out of range", i);
+    for (int i = 0; i < d->n_terms; ++i)
+        if (d->terms[i].atom < 0 || d->terms[i].atom >= d->n_atoms || d->terms[i].den >= d->n_atoms)
+            MCX_FAIL(h, -3, "mcx_book_create: term %d references a bad atom", i);
+    for (int i = 0; i < d->n_events; ++i) {
+        const mcx_event& e = d->events[i];
+        if (e.kind < MCX_EV_CASHFLOW || e.kind > MCX_EV_EXPO_BS) MCX_FAIL(h, -3, "mcx_book_create: event %d has a bad kind", i);
+        if (e.num_atom < 0 || e.num_atom >= d->n_atoms || e.x_atom >= d->n_atoms) MCX_FAIL(h, -3, "mcx_book_create: event %d atoms", i);
+        if (e.term_begin < 0 || e.term_end < e.term_begin || e.term_end > d->n_terms) MCX_FAIL(h, -3, "mcx_book_create: event %d terms", i);
+        if (e.coeff_off >= 0 && e.coeff_off + MCX_MAX_STATES * d->n_basis > d->n_coeffs + MCX_MAX_STATES * d->n_basis)
+            MCX_FAIL(h, -3, "mcx_book_create: event %d coefficient offset", i);
+        if ((e.kind == MCX_EV_EXERCISE && e.coeff_off >= 0 && e.x_atom < 0) || (e.kind >= MCX_EV_EXPO_POLY && e.x_atom < 0))
+            MCX_FAIL(h, -3, "mcx_book_create: event %d needs an explanatory atom", i);
+        if (e.kind >= MCX_EV_EXPO_POLY && (e.expo_row < 0 || e.expo_row >= d->n_expo_rows)) MCX_FAIL(h, -3, "mcx_book_create: event %d row", i);
+    }
+    for (int p = 0; p < d->n_products; ++p) {
+        const mcx_product& pr = d->products[p];
+        if (pr.ev_begin < 0 || pr.ev_end < pr.ev_begin || pr.ev_end > d->n_events || pr.cf_begin < 0 || pr.cf_end < pr.cf_begin ||
+            pr.cf_end > d->n_events || pr.netting_set < 0 || pr.netting_set >= d->n_netting_sets || pr.n_states < 1 ||
+            pr.n_states > MCX_MAX_STATES || pr.init_state < 0 || pr.init_state >= pr.n_states)
+            MCX_FAIL(h, -3, "mcx_book_create: product %d out of range", p);
+        for (int q = pr.ev_begin; q < pr.ev_end; ++q) {
+            const mcx_event& e = d->events[q];
+            if (e.coeff_off >= 0 && e.coeff_off + pr.n_states * d->n_basis > d->n_coeffs)
+                MCX_FAIL(h, -3, "mcx_book_create: product %d event %d coefficients out of range", p, q);
+        }
+        for (int q = pr.cf_begin; q < pr.cf_end; ++q) {
+            const mcx_event& e = d->events[q];
+            if (e.kind > MCX_EV_EXERCISE) MCX_FAIL(h, -3, "mcx_book_create: product %d cf event %d is not a cash event", p, q);
+            if (e.coeff_off >= 0 && e.coeff_off + pr.n_states * d->n_basis > d->n_coeffs)
+                MCX_FAIL(h, -3, "mcx_book_create: product %d cf event %d coefficients out of range", p, q);
+        }
+    }
+    MCX_HIP(h, hipSetDevice(h->device));
+    mcx_book* b = new mcx_book();
+    b->n_atoms = d->n_atoms; b->n_terms = d->n_terms; b->n_events = d->n_events; b->n_products = d->n_products;
+    b->n_netting_sets = d->n_netting_sets; b->n_expo_rows = d->n_expo_rows; b->n_basis = d->n_basis; b->n_coeffs = d->n_coeffs;
+    b->want_cfs = d->want_cfs; b->want_expo = d->want_expo; b->n_state = d->n_state;
+    b->h_atoms.assign(d->atoms, d->atoms + d->n_atoms);
+
+    std::vector<DevAtom> atoms(d->n_atoms > 0 ? d->n_atoms : 1);
+    for (int i = 0; i < d->n_atoms; ++i) atoms[i] = flat_atom(d->atoms[i]);
+    std::vector<DevTerm> terms(d->n_terms > 0 ? d->n_terms : 1);
+    for (int i = 0; i < d->n_terms; ++i) {
+        terms[i].w = d->terms[i].w;
+        terms[i].atom = flat_atom(d->atoms[d->terms[i].atom]);
+        terms[i].den = d->terms[i].den;
+        terms[i].pad = 0;
+    }
+    std::vector<DevEvent> events(d->n_events > 0 ? d->n_events : 1);
+    DevAtom none; memset(&none, 0, sizeof(none)); none.col = -1;
+    for (int i = 0; i < d->n_events; ++i) {
+        const mcx_event& e = d->events[i];
+        DevEvent& o = events[i];
+        memset(&o, 0, sizeof(o));
+        o.kind = e.kind; o.term_begin = e.term_begin; o.term_end = e.term_end; o.coeff_off = e.coeff_off; o.row = e.expo_row;
+        o.strike = e.strike; o.sign = e.sign;
+        for (int q = 0; q < 4; ++q) o.aux[q] = e.aux[q];
+        o.num = flat_atom(d->atoms[e.num_atom]);
+        o.x = e.x_atom >= 0 ? flat_atom(d->atoms[e.x_atom]) : none;
+    }
+    // exposure rows: the first writer of a (netting set, row) stores, later ones accumulate; rows nobody writes need a memset
+    b->ns_has_writer.assign((size_t)d->n_netting_sets * (d->n_expo_rows > 0 ? d->n_expo_rows : 1), 0);
+    b->h_products.resize(d->n_products);
+    for (int p = 0; p < d->n_products; ++p) {
+        const mcx_product& pr = d->products[p];
+        DevProduct& o = b->h_products[p];
+        o.ev_begin = pr.ev_begin; o.ev_end = pr.ev_end; o.cf_begin = pr.cf_begin; o.cf_end = pr.cf_end;
+        o.netting_set = pr.netting_set; o.init_state = pr.init_state; o.n_states = pr.n_states; o.flags = pr.flags;
+        for (int q = pr.ev_begin; q < pr.ev_end; ++q) {
+            DevEvent& e = events[q];
+            e.netting_set = pr.netting_set;
+            if (e.kind >= MCX_EV_EXPO_POLY) {
+                uint8_t& seen = b->ns_has_writer[(size_t)pr.netting_set * d->n_expo_rows + e.row];
+                e.flags = seen ? 1 : 0;
+                seen = 1;
+            }
+        }
+    }
+    b->expo_needs_memset = false;
+    if (d->want_expo)
+        for (size_t q = 0; q < (size_t)d->n_netting_sets * d->n_expo_rows; ++q)
+            if (!b->ns_has_writer[q]) b->expo_needs_memset = true;
+
+    b->d_atoms = nullptr; b->d_terms = nullptr; b->d_events = nullptr; b->d_products = nullptr; b->d_coeffs = nullptr;
+    MCX_HIP(h, hipMalloc(&b->d_atoms, sizeof(DevAtom) * atoms.size()));
+    MCX_HIP(h, hipMalloc(&b->d_terms, sizeof(DevTerm) * terms.size()));
+    MCX_HIP(h, hipMalloc(&b->d_events, sizeof(DevEvent) * events.size()));
+    MCX_HIP(h, hipMalloc(&b->d_products, sizeof(DevProduct) * (b->h_products.size() ? b->h_products.size() : 1)));
+    MCX_HIP(h, hipMalloc(&b->d_coeffs, sizeof(double) * (size_t)(d->n_coeffs > 0 ? d->n_coeffs : 1)));
+    MCX_HIP(h, hipMemcpy(b->d_atoms, atoms.data(), sizeof(DevAtom) * atoms.size(), hipMemcpyHostToDevice));
+    MCX_HIP(h, hipMemcpy(b->d_terms, terms.data(), sizeof(DevTerm) * terms.size(), hipMemcpyHostToDevice));
+    MCX_HIP(h, hipMemcpy(b->d_events, events.data(), sizeof(DevEvent) * events.size(), hipMemcpyHostToDevice));
+    if (!b->h_products.empty())
+        MCX_HIP(h, hipMemcpy(b->d_products, b->h_products.data(), sizeof(DevProduct) * b->h_products.size(), hipMemcpyHostToDevice));
+    if (d->n_coeffs > 0)
+        MCX_HIP(h, hipMemcpy(b->d_coeffs, d->coeffs, sizeof(double) * (size_t)d->n_coeffs, hipMemcpyHostToDevice));
+    *out = b;
+    return 0;
+}
+
+extern "C" void mcx_book_destroy(mcx_book* b)
+{
+    if (!b) return;
+    hipFree(b->d_atoms); hipFree(b->d_terms); hipFree(b->d_events); hipFree(b->d_products); hipFree(b->d_coeffs);
+    delete b;
+}
+
+extern "C" int mcx_book_set_coeffs(mcx_handle* h, mcx_book* b, int64_t offset, int64_t count, const double* h_coeffs, void* stream)
+{
+    if (!h || !b || !h_coeffs) return -1;
+    if (offset < 0 || count < 0 || offset + count > b->n_coeffs) MCX_FAIL(h, -2, "mcx_book_set_coeffs: range out of bounds");
+    if (count == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    // stage through pinned memory so the copy is stream-ordered with the kernels that read the coefficients
+    if ((size_t)count * sizeof(double) <= h->pinned_bytes) {
+        MCX_HIP(h, hipStreamSynchronize(s));
+        memcpy(h->h_pinned, h_coeffs, (size_t)count * sizeof(double));
+        MCX_HIP(h, hipMemcpyAsync(b->d_coeffs + offset, h->h_pinned, (size_t)count * sizeof(double), hipMemcpyHostToDevice, s));
+        MCX_HIP(h, hipStreamSynchronize(s));
+    } else {
+        MCX_HIP(h, hipStreamSynchronize(s));
+        MCX_HIP(h, hipMemcpy(b->d_coeffs + offset, h_coeffs, (size_t)count * sizeof(double), hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+// ---- shared helpers ---------------------------------------------------------------------------------------------------
+int mcx_upload_unsec(mcx_handle* h, const mcx_unsecured_desc* u, DevUnsec* out, int32_t** d_tmp, hipStream_t s)
+{
+    if (u->n_dates < 1 || u->n_dates > MCX_MAX_METRIC_DATES) MCX_FAIL(h, -2, "unsecured desc: n_dates %d out of range", u->n_dates);
+    int32_t* d = nullptr;
+    MCX_HIP(h, hipMalloc(&d, sizeof(int32_t) * 2 * (size_t)u->n_dates));
+    MCX_HIP(h, hipMemcpyAsync(d, u->row, sizeof(int32_t) * u->n_dates, hipMemcpyHostToDevice, s));
+    if (u->delayed) MCX_HIP(h, hipMemcpyAsync(d + u->n_dates, u->delayed, sizeof(int32_t) * u->n_dates, hipMemcpyHostToDevice, s));
+    MCX_HIP(h, hipStreamSynchronize(s));     // host arrays may be transient
+    out->n_dates = u->n_dates; out->collateralized = u->collateralized; out->threshold = u->threshold;
+    out->row = d; out->delayed = u->delayed ? d + u->n_dates : nullptr;
+    *d_tmp = d;
+    return 0;
+}
+
+namespace {
+// sums per-block partials: partials [n_blocks][n_records][2] -> out [n_records] as mcx_acc
+__global__ void k_finish_acc(const double* __restrict__ partials, int n_records, int n_blocks, double n_paths,
+                             const double* __restrict__ shifts, mcx_acc* __restrict__ out)
+{
+    const int r = blockIdx.x;
+    __shared__ double lds[8];
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = threadIdx.x; b < n_blocks; b += blockDim.x) {
+        s1 += partials[((int64_t)b * n_records + r) * 2 + 0];
+        s2 += partials[((int64_t)b * n_records + r) * 2 + 1];
+    }
+    s1 = block_sum(s1, lds);
+    s2 = block_sum(s2, lds + 4);
+    if (threadIdx.x == 0) {
+        out[r].n = n_paths; out[r].shift = shifts[r]; out[r].s1 = s1; out[r].s2 = s2;
+    }
+}
+}  // namespace
+
+int mcx_finish_acc(mcx_handle* h, const double* d_partials, int n_records, int n_blocks, double n_paths,
+                   const double* d_shifts, mcx_acc* h_out, hipStream_t s)
+{
+    if ((size_t)n_records * sizeof(mcx_acc) > h->pinned_bytes) MCX_FAIL(h, -2, "too many accumulator records");
+    mcx_acc* d_out = nullptr;
+    MCX_HIP(h, hipMalloc(&d_out, sizeof(mcx_acc) * (size_t)n_records));
+    hipLaunchKernelGGL(k_finish_acc, dim3(n_records), dim3(MCX_BLOCK), 0, s, d_partials, n_records, n_blocks, n_paths, d_shifts, d_out);
+    MCX_HIP(h, hipGetLastError());
+    MCX_HIP(h, hipMemcpyAsync(h->h_pinned, d_out, sizeof(mcx_acc) * (size_t)n_records, hipMemcpyDeviceToHost, s));
+    MCX_HIP(h, hipStreamSynchronize(s));
+    memcpy(h_out, h->h_pinned, sizeof(mcx_acc) * (size_t)n_records);
+    MCX_HIP(h, hipFree(d_out));
+    return 0;
+}

@@ -1,0 +1,179 @@
+// mcx_internal.h — private layout of libmcx_hip.so (gfx950 / CDNA4 only).
+// Device-side tables are flattened copies of the descriptors of include/mcx.h, built once at *_create time.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/mcx.h"
+
+#define MCX_WAVE 64           // CDNA4 wavefront
+#define MCX_BLOCK 256         // 4 waves: one per SIMD of a CU
+#define MCX_MAX_PARTIAL_BLOCKS 1024
+
+struct mcx_handle {
+    int device;
+    int n_cu;
+    std::string err;
+    double* d_ws;          // reduction workspace (partials)
+    size_t ws_bytes;
+    void* h_pinned;        // pinned staging for small device->host results
+    size_t pinned_bytes;
+    hipDeviceProp_t prop;
+};
+
+#define MCX_FAIL(h, code, ...)                                   \
+    do {                                                         \
+        char _b[512];                                            \
+        snprintf(_b, sizeof(_b), __VA_ARGS__);                   \
+        (h)->err = _b;                                           \
+        return (code);                                           \
+    } while (0)
+
+#define MCX_HIP(h, expr)                                                                              \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess) MCX_FAIL(h, -100 - (int)_e, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+// ---- flattened device records ---------------------------------------------------------------------------------------
+struct DevAtom {            // value = a + d*x + b*exp(c0 + c1*x), x = paths[(t_idx*D + col)*ld + i]
+    int32_t t_idx, col;
+    double a, d, b, c0, c1;
+};
+
+struct DevTerm {
+    double w;
+    DevAtom atom;
+    int32_t den;            // -1 or index into DevBook::atoms
+    int32_t pad;
+};
+
+struct DevEvent {
+    int32_t kind, flags;    // flags bit0: exposure row is accumulated (+=) instead of stored
+    int32_t term_begin, term_end;
+    int32_t coeff_off, row;
+    int32_t netting_set, pad;
+    double strike, sign;
+    double aux[4];
+    DevAtom num;
+    DevAtom x;
+};
+
+struct DevProduct {
+    int32_t ev_begin, ev_end, cf_begin, cf_end;
+    int32_t netting_set, init_state, n_states, flags;
+};
+
+struct mcx_book {
+    int n_atoms, n_terms, n_events, n_products, n_netting_sets, n_expo_rows, n_basis, n_coeffs, want_cfs, want_expo;
+    int n_state;                   // inferred: max col + 1 is NOT used; D comes from the sim (passed via paths layout)
+    DevAtom* d_atoms;
+    DevTerm* d_terms;
+    DevEvent* d_events;
+    DevProduct* d_products;
+    double* d_coeffs;
+    std::vector<mcx_atom> h_atoms;
+    std::vector<DevProduct> h_products;
+    std::vector<uint8_t> ns_has_writer;   // [n_netting_sets * n_expo_rows]
+    bool expo_needs_memset;
+};
+
+struct mcx_sim {
+    mcx_sim_desc desc;             // host copy (pointer members unused after create)
+    mcx_step* d_steps;
+    double* d_chol;
+    double* d_aux;
+    int n_state_total;
+    int state_dim[MCX_MAX_SLOTS];
+};
+
+// ---- device helpers -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double dev_atom(const DevAtom& a, const double* __restrict__ paths, int64_t D, int64_t ld, int64_t i)
+{
+    double x = 0.0;
+    if (a.col >= 0) x = paths[((int64_t)a.t_idx * D + a.col) * ld + i];
+    double v = fma(a.d, x, a.a);
+    if (a.b != 0.0) v = fma(a.b, exp(fma(a.c1, x, a.c0)), v);
+    return v;
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, MCX_WAVE);
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_down(v, off, MCX_WAVE));
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, MCX_WAVE));
+    return v;
+}
+
+// sum over a 256-thread block; result valid in thread 0. `lds` must hold >= 4 doubles; includes the barriers it needs.
+__device__ __forceinline__ double block_sum(double v, double* lds)
+{
+    v = wave_sum(v);
+    const int lane = threadIdx.x & (MCX_WAVE - 1), w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) lds[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + MCX_WAVE - 1) >> 6;
+        for (int q = 0; q < nw; ++q) r += lds[q];
+    }
+    return r;
+}
+
+static inline int mcx_grid_for(int64_t n, int block, int cap)
+{
+    int64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+// unsecured-exposure descriptor copied by value into kernel arguments (K4/K5)
+#define MCX_MAX_METRIC_DATES 512
+struct DevUnsec {
+    int32_t n_dates, collateralized;
+    double threshold;
+    const int32_t* row;       // device
+    const int32_t* delayed;   // device or nullptr
+};
+
+__device__ __forceinline__ double dev_thr(double x, double h)
+{
+    if (h == 0.0) return x;
+    return x > h ? x - h : (x < -h ? x + h : 0.0);
+}
+
+__device__ __forceinline__ double dev_unsec(const DevUnsec& u, const double* __restrict__ expo, int64_t ld, int m, int64_t i)
+{
+    double e = expo[(int64_t)u.row[m] * ld + i];
+    if (!u.collateralized) return dev_thr(e, u.threshold);
+    double coll = 0.0;
+    if (u.delayed) {
+        int dm = u.delayed[m];
+        if (dm >= 0) coll = dev_thr(expo[(int64_t)dm * ld + i], u.threshold);
+    }
+    return e - coll;
+}
+
+// host-side helpers implemented in mcx_api.hip
+int mcx_upload_unsec(mcx_handle* h, const mcx_unsecured_desc* u, DevUnsec* out, int32_t** d_tmp, hipStream_t s);
+int mcx_finish_acc(mcx_handle* h, const double* d_partials, int n_records, int n_blocks, double n_paths,
+                   const double* d_shifts, mcx_acc* h_out, hipStream_t s);

@@ -453,36 +453,49 @@ class SimulationController:
         return [(float(v), float(e)) for v, e in res]
 
     # ---- entry point (controller.py:663-709) ------------------------------------------------------------------------
+    def prepare(self):
+        """everything before the main simulation: descriptor compilation + (if needed) pre-simulation and LSM regression
+        (the reference's perform_prepocessing, controller.py:257-292)"""
+        be = self.backend
+        self._shard = Shard()
+        self._compile_all()
+        self.sim_plan = SimPlan(self.model, self.simulation_timeline.numpy(), self.simulation_scheme, self.num_steps)
+        self._sim = be.sim_create(self.sim_plan)
+        if self.requires_regression:
+            self._perform_regression(self._shard, self.sim_plan, self._sim)
+        off, n_local = self._shard.split(self.num_paths_mainsim)
+        self._main_engine = MonteCarloEngine(self.simulation_timeline, self.simulation_scheme, self.model, n_local,
+                                             self.num_steps, is_pre_simulation=False, path_offset=off, backend=be,
+                                             plan=self.sim_plan, sim=self._sim)
+        if "main" in self._inject:
+            self._main_engine.inject_z, self._main_engine.inject_u = self._inject["main"]
+        be.synchronize()
+
+    def main_pass(self, paths_out=None):
+        """ONE pass of the hot path over this rank's shard of the main-simulation paths: K1 path generation, K2 book
+        evaluation, K4/K5 reductions (+ the accumulator collectives). Returns the nested metric results."""
+        be = self.backend
+        paths = self._main_engine.generate_paths_native(out=paths_out)
+        cfs, expo = be.eval_book(self.book, paths) if self._mc_products else (None, None)
+        self.last_state.update(paths=paths, cfs=cfs, expo=expo)
+        return self._evaluate_all(self._shard, cfs, expo, paths)
+
     def run_simulation(self) -> SimulationResults:
         if self.differentiate:
             from ..aad import run_with_tangents
             return run_with_tangents(self)
         t0 = time.perf_counter()
         be = self.backend
-        shard = Shard()
-        self._compile_all()
-        sim_plan = SimPlan(self.model, self.simulation_timeline.numpy(), self.simulation_scheme, self.num_steps)
-        sim = be.sim_create(sim_plan)
-        self.sim_plan = sim_plan
-        if self.requires_regression:
-            self._perform_regression(shard, sim_plan, sim)
-        be.synchronize()
+        self.prepare()
         t1 = time.perf_counter()
-
-        off, n_local = shard.split(self.num_paths_mainsim)
-        eng = MonteCarloEngine(self.simulation_timeline, self.simulation_scheme, self.model, n_local, self.num_steps,
-                               is_pre_simulation=False, path_offset=off, backend=be, plan=sim_plan, sim=sim)
-        if "main" in self._inject:
-            eng.inject_z, eng.inject_u = self._inject["main"]
-        self._main_engine = eng
-        paths = eng.generate_paths_native()
+        paths = self._main_engine.generate_paths_native()
         be.synchronize()
         t2 = time.perf_counter()
         cfs, expo = be.eval_book(self.book, paths) if self._mc_products else (None, None)
         be.synchronize()
         t3 = time.perf_counter()
         self.last_state.update(paths=paths, cfs=cfs, expo=expo)
-        results = self._evaluate_all(shard, cfs, expo, paths)
+        results = self._evaluate_all(self._shard, cfs, expo, paths)
         t4 = time.perf_counter()
         self.timings = dict(preprocessing=t1 - t0, path_generation=t2 - t1, request_resolution=0.0,
                             valuation=t3 - t2, metrics=t4 - t3, total=t4 - t0)

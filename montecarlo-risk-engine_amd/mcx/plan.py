@@ -152,6 +152,7 @@ class BookPlan:
         d.n_atoms, d.n_terms, d.n_events, d.n_products = len(self.atoms), len(self.terms), len(self.events), len(products)
         d.n_netting_sets, d.n_expo_rows, d.n_basis, d.n_coeffs = n_netting_sets, n_expo_rows, comp.n_basis, len(self.coeffs)
         d.want_cfs, d.want_expo = int(want_cfs), int(want_expo)
+        d.n_state = n_state
         d.atoms, d.terms, d.events, d.products = (_abi.ptr(self.atoms), _abi.ptr(self.terms), _abi.ptr(self.events),
                                                   _abi.ptr(self.products))
         d.coeffs = _abi.ptr(self.coeffs)
