@@ -159,9 +159,10 @@ __global__ __launch_bounds__(MCX_BLOCK) void k3_step_mfma(const K3Args a)
         }
         __builtin_amdgcn_wave_barrier();
     }
-    // D[row = 4*(lane/16) + r][col = lane%16] = accm[r]
+    // accumulator layout of v_mfma_f64_16x16x4_f64 (probed on gfx950 with tools/mfma_probe.hip):
+    //   D[row = 4*r + lane/16][col = lane%16] = accm[r]
 #pragma unroll
-    for (int r = 0; r < 4; ++r) gram[wv][(4 * pk + r) * 16 + fi] = accm[r];
+    for (int r = 0; r < 4; ++r) gram[wv][(4 * r + pk) * 16 + fi] = accm[r];
     __syncthreads();
     if (threadIdx.x < NM) {
         const int q = threadIdx.x;
