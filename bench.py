@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--paths", type=int, default=1 << 20, help="main-simulation paths PER GPU")
     ap.add_argument("--presim", type=int, default=131072, help="pre-simulation (LSM) paths PER GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--unfused", action="store_true", help="run K1, K2, K4 as separate launches (materialised tensors)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -109,18 +110,25 @@ def main():
         torch.cuda.synchronize()
 
     res = None
+    if args.unfused:
+        sc._fused = None
     for _ in range(args.warmup):
-        res = sc.main_pass(paths_buf)
+        res = sc.main_pass(paths_buf if sc._fused is None else None)
     # per-kernel device time of the dominant kernel (K1) with HIP events on the launch stream
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
+    fused = sc._fused is not None
     for k in range(args.steps):
         ev[k][0].record()
-        paths = sc._main_engine.generate_paths_native(out=paths_buf)
-        ev[k][1].record()
-        cfs, expo = be.eval_book(sc.book, paths)
-        res = sc._evaluate_all(sc._shard, cfs, expo, paths)
+        if fused:
+            res = sc._fused_pass()               # one launch: K1+K2+K4 (+ block merge, record copy, rank gather)
+            ev[k][1].record()
+        else:
+            paths = sc._main_engine.generate_paths_native(out=paths_buf)
+            ev[k][1].record()
+            cfs, expo = be.eval_book(sc.book, paths)
+            res = sc._evaluate_all(sc._shard, cfs, expo, paths)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -133,9 +141,10 @@ def main():
         cva, err = res[0][0][0]
         total_paths = n_local * world if world == 1 else args.paths * world
         value = total_paths * S * args.steps / dt
-        k1_bytes = 8.0 * T * D * n_local                       # algorithmic bytes of K1: the engine's output tensor
-        achieved = k1_bytes / (k1_ms * 1e-3) / 1e9
         pass_bytes = 8.0 * (2 * T * D + 2 * E + 2) * n_local   # SURVEY.md §8d B_path for the whole pass
+        # dominant kernel: the fused pass carries the whole pass's algorithmic bytes; unfused K1 only its output tensor
+        k1_bytes = pass_bytes if fused else 8.0 * T * D * n_local
+        achieved = k1_bytes / (k1_ms * 1e-3) / 1e9
         out = {
             "metric": "path-steps/sec at 1M paths x 250 steps; PV/CVA rel-error vs CPU ref",
             "value": value, "unit": "path-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -144,7 +153,7 @@ def main():
             "config": {"workload": "Vasicek+CIR++ (rho=0.5) payer IRS CVA, Euler, 51 dates x 5 sub-steps (SURVEY §8d config 3)",
                        "paths_per_gpu": n_local, "steps_per_path": S, "state_dim": D, "stored_dates": T,
                        "exposure_dates": E, "presim_paths_per_gpu": args.presim, "parallelism": f"paths x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "k1_paths<2,2> (fused Philox+Box-Muller+Cholesky+Euler)",
+            "roofline": {"bound": "hbm", "kernel": "kf_fused<2,2> (K1+K2+K4 in one launch)" if fused else "k1_paths<2,2> (Philox+Box-Muller+Cholesky+Euler)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel_ms": k1_ms, "algorithmic_bytes_per_launch": k1_bytes,
                          "whole_pass_algorithmic_GBs": pass_bytes / (dt / args.steps) / 1e9},

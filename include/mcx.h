@@ -200,9 +200,42 @@ typedef struct {
     double s2;      /* sum (x - shift)^2            */
 } mcx_acc;
 
+/* ---- fused main-simulation pass (K1 + K2 + K4 in one launch) --------------------------------------------------------
+ * The reference materialises paths [N,T,D], ~5 resolved request vectors per date and exposures [E,N] between its phases
+ * (controller.py:677-694).  For the library's own metrics nothing of that needs to exist in HBM: the fused kernel keeps a
+ * path's state in registers, evaluates the book's events of each stored date right after the sub-steps that reach it and
+ * reduces PV / EPE / ENE / CVA on the fly.  Paths / exposures / cashflows are still written when the caller passes
+ * buffers (PFE select, pluggable metrics, inspection).  Not every book is fusable (collateral look-back, the unequal-tenor
+ * swap quirk): mcx_fused_create then returns MCX_E_NOT_FUSABLE and the caller uses K1/K2/K4. */
+#define MCX_E_NOT_FUSABLE (-10)
+#define MCX_FUSED_MAX_NS 4
+#define MCX_FUSED_MAX_STATEFUL 4
+
+typedef struct {
+    int32_t netting_set;
+    int32_t n_dates;            /* metric exposure dates of this netting set                              */
+    int32_t want_profiles;      /* 2*n_dates records {relu(u_m), -relu(-u_m)}  (EPE / ENE / CE)           */
+    int32_t want_cva;           /* 1 record: (1-R) sum_m relu(u_m) S(0,t_m) (1 - S(t_m,t_{m+1}))           */
+    double  threshold;          /* symmetric threshold (netting_set.py:48-72); collateral is NOT fusable   */
+    double  recovery;
+    const int32_t* row;         /* [n_dates] exposure row of each metric date                              */
+    const int32_t* surv_atoms;  /* [n_dates-1] (want_cva)                                                  */
+    const int32_t* cond_atoms;  /* [n_dates-1] (want_cva)                                                  */
+} mcx_fused_ns_desc;
+
+typedef struct {
+    int32_t n_netting_sets;     /* entries of ns[] (<= MCX_FUSED_MAX_NS)                                   */
+    int32_t want_pv;            /* 1 PV record per netting set (pv_metric.py:17-18)                        */
+    int32_t n_expo_rows;
+    int32_t reserved;
+    const int32_t* row_t_idx;   /* [n_expo_rows] timeline index of every exposure row                      */
+    const mcx_fused_ns_desc* ns;
+} mcx_fused_desc;
+
 typedef struct mcx_handle mcx_handle;
 typedef struct mcx_sim    mcx_sim;
 typedef struct mcx_book   mcx_book;
+typedef struct mcx_fused  mcx_fused;
 
 int         mcx_abi_version(void);
 int         mcx_create(mcx_handle** out, int device_id);
@@ -227,6 +260,15 @@ int  mcx_eval_book(mcx_handle* h, const mcx_book* book, const double* d_paths, i
 /* materialise resolved requests for pluggable Metric subclasses (request_interface.py:115-130): d_out [n_ids][ld_out] */
 int  mcx_resolve_atoms(mcx_handle* h, const mcx_book* book, const int32_t* h_atom_ids, int32_t n_ids,
                        const double* d_paths, int64_t n_paths, int64_t ld, double* d_out, int64_t ld_out, void* stream);
+
+/* fused pass. h_out receives, for every entry of desc.ns in order: [PV record if want_pv][2*n_dates profile records if
+ * want_profiles][CVA record if want_cva].  d_paths / d_cfs / d_expo may each be NULL (not materialised). */
+int  mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_book* book, const mcx_fused_desc* desc, mcx_fused** out);
+void mcx_fused_destroy(mcx_fused* f);
+int  mcx_fused_num_records(const mcx_fused* f);
+int  mcx_fused_run(mcx_handle* h, const mcx_fused* f, uint64_t seed, uint64_t path_offset, int64_t n_paths,
+                   double* d_paths, int64_t ld, double* d_cfs, double* d_expo, int64_t ld_out,
+                   const double* d_inject_z, const double* d_inject_u, mcx_acc* h_out, void* stream);
 
 /* K3 — Longstaff-Schwartz normal equations (controller/controller.py:316-374).
  * mcx_lsm_stats: h_out[2*i+0] = min x_i, h_out[2*i+1] = max x_i over local paths for each explanatory atom (basis centring /

@@ -1,0 +1,520 @@
+// kf_fused.hip — the fused main-simulation pass: K1 (Philox + Box-Muller + Cholesky + SDE step) + K2 (requests,
+// cashflows, exposures) + K4 (PV / EPE / ENE / CVA reductions) in ONE launch, no intermediate tensor in HBM.
+//
+// Reference dataflow replaced (controller/controller.py:677-694): generate_paths -> paths[N,T,D] (1.6 GB at config 3)
+// -> resolve_requests (~2.4 GB) -> evaluate_products -> exposures[E,N] (0.4 GB) -> metric reductions.  Here a lane keeps
+// its path's state in VGPRs, runs the book's events of a timeline date right after the sub-steps that reach it (every
+// atom of such an event reads the state of THAT date), and folds the result into per-path accumulators (cashflows, CVA
+// integrand) and per-date block accumulators (EPE / ENE) that live in LDS across the block's path tiles.
+//
+// Block-level reduction design: per record r the block keeps a shift c_r (value of the first path it sees) and, per wave,
+// the pair (sum (x-c), sum (x-c)^2) in LDS; every date costs one wave64 shuffle reduction per record.  Blocks write one
+// (n, c, s1, s2) record each; a tiny second kernel merges blocks with Chan's update (deterministic, no float atomics).
+#include "mcx_device.h"
+
+#include <algorithm>
+
+namespace {
+
+struct FAtom {             // value = a + d*x + b*exp(c0 + c1*x), x = register `reg` of the lane (reg < 0: x = 0)
+    int32_t reg, pad;
+    double a, d, b, c0, c1;
+};
+struct FTerm { double w; FAtom atom; };
+struct FEvent {
+    int32_t kind, flags;
+    int32_t term_begin, term_end;
+    int32_t coeff_off, row;
+    int32_t ns, sidx;          // netting-set slot (0..3), stateful-product slot (0..3) or -1
+    int32_t init_state, pad;
+    double strike, sign;
+    double aux[4];
+    FAtom num, x;
+};
+struct FMetricOp {             // one (netting set, metric date) pair, executed after the date's events
+    int32_t ns, m;
+    int32_t rec_profile;       // record index of relu(u) (rec+1 = -relu(-u)), -1: no profiles
+    int32_t has_cva;           // 1: m < n_dates-1 and CVA wanted
+    double threshold;
+    FAtom surv, cond;
+};
+
+struct FusedArgs {
+    K1Args k1;
+    const FTerm* __restrict__ terms;
+    const FEvent* __restrict__ events;
+    const FMetricOp* __restrict__ mops;
+    const int32_t* __restrict__ date_ev;      // [n_dates+1] event range per timeline date
+    const int32_t* __restrict__ date_mop;     // [n_dates+1]
+    const int32_t* __restrict__ date_row;     // [n_dates] exposure row of this timeline date or -1
+    const double* __restrict__ coeffs;
+    double* __restrict__ cfs;                 // nullable [NS][ld_out]
+    double* __restrict__ expo;                // nullable [NS][n_expo_rows][ld_out]
+    double* __restrict__ partials;            // [gridDim.x][n_rec][4]
+    int64_t ld_out;
+    int32_t n_dates, n_basis, n_ns, n_rec, n_expo_rows, n_stateful;
+    int32_t rec_pv[MCX_FUSED_MAX_NS];         // record index of the PV record of ns slot k, or -1
+    int32_t rec_cva[MCX_FUSED_MAX_NS];
+    double lgd[MCX_FUSED_MAX_NS];
+    int32_t init_state[MCX_FUSED_MAX_STATEFUL];
+};
+
+template <int NREG>
+__device__ __forceinline__ double f_atom(const FAtom& a, const double (&reg)[NREG])
+{
+    double x = 0.0;
+#pragma unroll
+    for (int q = 0; q < NREG; ++q) x = (a.reg == q) ? reg[q] : x;     // wave-uniform select
+    double v = fma(a.d, x, a.a);
+    if (a.b != 0.0) v = fma(a.b, exp(fma(a.c1, x, a.c0)), v);
+    return v;
+}
+
+__device__ __forceinline__ double f_poly(const double* __restrict__ c, int K, double x)
+{
+    double v = 0.0, xp = 1.0;
+    for (int k = 0; k < K; ++k) { v = fma(c[k], xp, v); xp *= x; }
+    return v;
+}
+
+__device__ __forceinline__ double f_norm_cdf(double x) { return 0.5 * (1.0 + erf(x * 0.70710678118654752440)); }
+
+// LDS layout: shift[n_rec] | acc[4 waves][n_rec][2]
+__device__ __forceinline__ void f_record(double v, bool live, int rec, int n_rec, bool first_tile, double* __restrict__ lds)
+{
+    if (first_tile) {                      // block-uniform: the first path the block sees fixes the record's shift
+        __syncthreads();
+        if (threadIdx.x == 0) lds[rec] = v;
+        __syncthreads();
+    }
+    const double c = lds[rec];
+    const double d = live ? v - c : 0.0;
+    const double s1 = wave_sum(d), s2 = wave_sum(d * d);
+    if ((threadIdx.x & 63) == 0) {
+        double* acc = lds + n_rec + ((threadIdx.x >> 6) * n_rec + rec) * 2;
+        acc[0] += s1;
+        acc[1] += s2;
+    }
+}
+
+template <int NSLOT, int NZ, bool INJECT>
+__global__ __launch_bounds__(MCX_BLOCK) void kf_fused(const FusedArgs a)
+{
+    constexpr int NREG = 2 * NSLOT;
+    extern __shared__ double lds[];
+    const K1Args& k = a.k1;
+    const int n_rec = a.n_rec;
+    for (int q = threadIdx.x; q < n_rec + 4 * n_rec * 2; q += MCX_BLOCK) lds[q] = 0.0;
+    __syncthreads();
+    const int64_t tiles = (k.n + MCX_BLOCK - 1) / MCX_BLOCK;
+    double n_block = 0.0;
+    const int D = k.n_state;
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const bool first_tile = tile == (int64_t)blockIdx.x;
+        const int64_t i_raw = tile * MCX_BLOCK + threadIdx.x;
+        const bool live = i_raw < k.n;
+        const int64_t i = live ? i_raw : k.n - 1;          // dead lanes shadow the last path (no stores, no contribution)
+        { const int64_t rest = k.n - tile * MCX_BLOCK; n_block += (double)(rest < MCX_BLOCK ? rest : MCX_BLOCK); }
+
+        double reg[NREG];                                  // reg[2s], reg[2s+1] = state of slot s
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            reg[2 * s] = k.init_state[k.slots[s].state_off];
+            reg[2 * s + 1] = (k.slots[s].kind == MCX_MODEL_BS) ? 0.0 : k.init_state[k.slots[s].state_off + 1];
+        }
+        double cfs[MCX_FUSED_MAX_NS] = {0.0, 0.0, 0.0, 0.0};
+        double cva[MCX_FUSED_MAX_NS] = {0.0, 0.0, 0.0, 0.0};
+        int est[MCX_FUSED_MAX_STATEFUL];
+#pragma unroll
+        for (int q = 0; q < MCX_FUSED_MAX_STATEFUL; ++q) est[q] = a.init_state[q];
+
+        auto on_date = [&](int t) {
+            if (k.paths && live) {
+#pragma unroll
+                for (int s = 0; s < NSLOT; ++s) {
+                    const int c = k.slots[s].state_off;
+                    k.paths[((int64_t)t * D + c) * k.ld + i] = reg[2 * s];
+                    if (k.slots[s].kind != MCX_MODEL_BS) k.paths[((int64_t)t * D + c + 1) * k.ld + i] = reg[2 * s + 1];
+                }
+            }
+            double e_ns[MCX_FUSED_MAX_NS] = {0.0, 0.0, 0.0, 0.0};
+            for (int q = a.date_ev[t]; q < a.date_ev[t + 1]; ++q) {
+                const FEvent& e = a.events[q];
+                const double num = f_atom<NREG>(e.num, reg);
+                double v = 0.0;
+                if (e.kind <= MCX_EV_EXERCISE) {
+                    double val = 0.0;
+                    for (int j = e.term_begin; j < e.term_end; ++j) val = fma(a.terms[j].w, f_atom<NREG>(a.terms[j].atom, reg), val);
+                    if (e.kind == MCX_EV_CASHFLOW) {
+                        v = val / num;
+                    } else {
+                        const double imm = fmax(e.sign * (val - e.strike), 0.0);
+                        if (e.kind == MCX_EV_OPTION) {
+                            v = imm / num;
+                        } else {
+                            int s = 0;
+#pragma unroll
+                            for (int w = 0; w < MCX_FUSED_MAX_STATEFUL; ++w) s = (e.sidx == w) ? est[w] : s;
+                            double cont = 0.0;
+                            if (e.coeff_off >= 0) cont = f_poly(a.coeffs + e.coeff_off + s * a.n_basis, a.n_basis, f_atom<NREG>(e.x, reg));
+                            const bool ex = (imm > cont) && (s > 0);
+                            v = ex ? imm / num : 0.0;
+#pragma unroll
+                            for (int w = 0; w < MCX_FUSED_MAX_STATEFUL; ++w) est[w] = (e.sidx == w && ex) ? s - 1 : est[w];
+                        }
+                    }
+#pragma unroll
+                    for (int w = 0; w < MCX_FUSED_MAX_NS; ++w) cfs[w] += (e.ns == w) ? v : 0.0;
+                } else {
+                    if (e.kind == MCX_EV_EXPO_POLY) {
+                        int s = e.init_state;
+#pragma unroll
+                        for (int w = 0; w < MCX_FUSED_MAX_STATEFUL; ++w) s = (e.sidx == w) ? est[w] : s;
+                        const double x = f_atom<NREG>(e.x, reg);
+                        v = (e.coeff_off >= 0 ? f_poly(a.coeffs + e.coeff_off + s * a.n_basis, a.n_basis, x) : 0.0) / num;
+                    } else if (e.aux[2] > 0.0) {
+                        const double spot = f_atom<NREG>(e.x, reg);
+                        const double sig = e.aux[0], rate = e.aux[1], tau = e.aux[2], Kx = e.strike;
+                        const double sq = sqrt(tau);
+                        const double d1 = (log(spot / Kx) + (rate + 0.5 * sig * sig) * tau) / (sig * sq);
+                        const double d2 = d1 - sig * sq;
+                        const double df = exp(-rate * tau);
+                        const double price = e.sign > 0.0 ? spot * f_norm_cdf(d1) - Kx * df * f_norm_cdf(d2)
+                                                          : Kx * df * f_norm_cdf(-d2) - spot * f_norm_cdf(-d1);
+                        v = price / num;
+                    }
+#pragma unroll
+                    for (int w = 0; w < MCX_FUSED_MAX_NS; ++w) e_ns[w] += (e.ns == w) ? v : 0.0;
+                }
+            }
+            const int row = a.date_row[t];
+            if (a.expo && row >= 0 && live) {
+                for (int w = 0; w < a.n_ns; ++w) {
+                    double ev = e_ns[0];
+#pragma unroll
+                    for (int q = 1; q < MCX_FUSED_MAX_NS; ++q) ev = (w == q) ? e_ns[q] : ev;
+                    a.expo[((int64_t)w * a.n_expo_rows + row) * a.ld_out + i] = ev;
+                }
+            }
+            for (int q = a.date_mop[t]; q < a.date_mop[t + 1]; ++q) {
+                const FMetricOp& mo = a.mops[q];
+                double e = e_ns[0];
+#pragma unroll
+                for (int w = 1; w < MCX_FUSED_MAX_NS; ++w) e = (mo.ns == w) ? e_ns[w] : e;
+                const double u = dev_thr(e, mo.threshold);
+                if (mo.rec_profile >= 0) {
+                    f_record(fmax(u, 0.0), live, mo.rec_profile, n_rec, first_tile, lds);
+                    f_record(fmin(u, 0.0), live, mo.rec_profile + 1, n_rec, first_tile, lds);
+                }
+                if (mo.has_cva) {
+                    const double sp = f_atom<NREG>(mo.surv, reg), cs = f_atom<NREG>(mo.cond, reg);
+                    const double inc = fmax(u, 0.0) * (sp * (1.0 - cs));
+#pragma unroll
+                    for (int w = 0; w < MCX_FUSED_MAX_NS; ++w) cva[w] += (mo.ns == w) ? inc : 0.0;
+                }
+            }
+        };
+
+        for (int t = 0; t < k.n_initial_store; ++t) on_date(t);
+        const uint64_t path = k.path_offset + (uint64_t)i;
+        for (int step = 0; step < k.n_steps; ++step) {
+            const mcx_step sp = k.steps[step];
+            double z[NZ], zc[NZ], u = 0.0;
+            if (INJECT) {
+#pragma unroll
+                for (int j = 0; j < NZ; ++j) z[j] = k.inject_z[((int64_t)step * NZ + j) * k.ld + i];
+                if (k.n_uniform) u = k.inject_u[(int64_t)step * k.ld + i];
+            } else {
+                double ua;
+#pragma unroll
+                for (int q = 0; q < (NZ + 1) / 2; ++q) {
+                    double z0, z1;
+                    draw_pair(k.seed, path, (uint32_t)step, (uint32_t)q, ua, z0, z1);
+                    z[2 * q] = z0;
+                    if (2 * q + 1 < NZ) z[2 * q + 1] = z1;
+                }
+                if (k.n_uniform) {
+                    double z0, z1;
+                    draw_pair(k.seed, path, (uint32_t)step, (uint32_t)((NZ + 1) / 2), u, z0, z1);
+                }
+            }
+            const double* __restrict__ L = k.chol + (int64_t)sp.chol_idx * NZ * NZ;
+#pragma unroll
+            for (int r = 0; r < NZ; ++r) {
+                double acc = 0.0;
+#pragma unroll
+                for (int c = 0; c <= r; ++c) acc += L[r * NZ + c] * z[c];
+                zc[r] = acc;
+            }
+            const double* __restrict__ ax = k.aux + (int64_t)step * NSLOT * MCX_AUX;
+#pragma unroll
+            for (int s = 0; s < NSLOT; ++s) {
+                const double zc0 = (NSLOT == 1) ? zc[0] : zc[s < NZ ? s : 0];
+                const double zc1 = (NSLOT == 1 && NZ > 1) ? zc[NZ > 1 ? 1 : 0] : 0.0;
+                step_slot(k.slots[s], k.scheme, k.flags | k.slots[s].flags, sp.dt, sp.sqrt_dt, ax + s * MCX_AUX,
+                          reg[2 * s], reg[2 * s + 1], zc0, zc1, u);
+            }
+            if (sp.store_idx >= 0) on_date(sp.store_idx);
+        }
+        // per-path quantities
+        for (int w = 0; w < a.n_ns; ++w) {
+            double cv = cfs[0], cc = cva[0];
+#pragma unroll
+            for (int q = 1; q < MCX_FUSED_MAX_NS; ++q) { cv = (w == q) ? cfs[q] : cv; cc = (w == q) ? cva[q] : cc; }
+            if (a.cfs && live) a.cfs[(int64_t)w * a.ld_out + i] = cv;
+            if (a.rec_pv[w] >= 0) f_record(cv, live, a.rec_pv[w], n_rec, first_tile, lds);
+            if (a.rec_cva[w] >= 0) f_record(cc * a.lgd[w], live, a.rec_cva[w], n_rec, first_tile, lds);
+        }
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < n_rec; r += MCX_BLOCK) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int w = 0; w < 4; ++w) { s1 += lds[n_rec + (w * n_rec + r) * 2]; s2 += lds[n_rec + (w * n_rec + r) * 2 + 1]; }
+        double* dst = a.partials + ((int64_t)blockIdx.x * n_rec + r) * 4;
+        dst[0] = n_block; dst[1] = lds[r]; dst[2] = s1; dst[3] = s2;
+    }
+}
+
+// merge per-block records (Chan, Golub, LeVeque pairwise update) -> out[r] = (n, mean, 0, M2)
+__global__ void kf_merge(const double* __restrict__ partials, int n_rec, int n_blocks, mcx_acc* __restrict__ out)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rec) return;
+    double N = 0.0, mean = 0.0, M2 = 0.0;
+    for (int b = 0; b < n_blocks; ++b) {
+        const double* p = partials + ((int64_t)b * n_rec + r) * 4;
+        const double n = p[0];
+        if (n <= 0.0) continue;
+        const double m = p[1] + p[2] / n;
+        const double q = fmax(p[3] - p[2] * p[2] / n, 0.0);
+        if (N == 0.0) { N = n; mean = m; M2 = q; }
+        else {
+            const double delta = m - mean, tot = N + n;
+            mean += delta * n / tot;
+            M2 += q + delta * delta * N * n / tot;
+            N = tot;
+        }
+    }
+    out[r].n = N; out[r].shift = mean; out[r].s1 = 0.0; out[r].s2 = M2;
+}
+
+template <int NSLOT, int NZ>
+void launch_kf(const FusedArgs& a, int grid, size_t lds, bool inject, hipStream_t s)
+{
+    if (inject) hipLaunchKernelGGL((kf_fused<NSLOT, NZ, true>), dim3(grid), dim3(MCX_BLOCK), lds, s, a);
+    else hipLaunchKernelGGL((kf_fused<NSLOT, NZ, false>), dim3(grid), dim3(MCX_BLOCK), lds, s, a);
+}
+
+}  // namespace
+
+struct mcx_fused {
+    const mcx_sim* sim;
+    const mcx_book* book;
+    int n_rec, n_ns, n_dates, n_expo_rows, n_stateful, want_pv;
+    FTerm* d_terms;
+    FEvent* d_events;
+    FMetricOp* d_mops;
+    int32_t* d_date_ev;
+    int32_t* d_date_mop;
+    int32_t* d_date_row;
+    int32_t rec_pv[MCX_FUSED_MAX_NS], rec_cva[MCX_FUSED_MAX_NS];
+    double lgd[MCX_FUSED_MAX_NS];
+    int32_t init_state[MCX_FUSED_MAX_STATEFUL];
+    double* d_partials;
+    size_t partial_bytes;
+    mcx_acc* d_out;
+};
+
+extern "C" void mcx_fused_destroy(mcx_fused* f)
+{
+    if (!f) return;
+    hipFree(f->d_terms); hipFree(f->d_events); hipFree(f->d_mops); hipFree(f->d_date_ev); hipFree(f->d_date_mop);
+    hipFree(f->d_date_row); hipFree(f->d_partials); hipFree(f->d_out);
+    delete f;
+}
+
+extern "C" int mcx_fused_num_records(const mcx_fused* f) { return f ? f->n_rec : -1; }
+
+extern "C" int mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_book* book, const mcx_fused_desc* d, mcx_fused** out)
+{
+    if (!h || !sim || !book || !d || !out) return -1;
+    const mcx_sim_desc& sd = sim->desc;
+    if (book->n_state != sd.n_state) MCX_FAIL(h, -2, "mcx_fused_create: book and sim disagree on the state dimension");
+    if (d->n_netting_sets < 1 || d->n_netting_sets > MCX_FUSED_MAX_NS || d->n_netting_sets != book->n_netting_sets)
+        MCX_FAIL(h, MCX_E_NOT_FUSABLE, "not fusable: %d netting sets (max %d)", book->n_netting_sets, MCX_FUSED_MAX_NS);
+    if (d->n_expo_rows != book->n_expo_rows) MCX_FAIL(h, -2, "mcx_fused_create: n_expo_rows mismatch");
+    const int T = sd.n_dates;
+    // state column -> lane register
+    int col_reg[MCX_MAX_STATE];
+    for (int s = 0; s < sd.n_slots; ++s) {
+        col_reg[sd.slots[s].state_off] = 2 * s;
+        if (sd.slots[s].kind != MCX_MODEL_BS) col_reg[sd.slots[s].state_off + 1] = 2 * s + 1;
+    }
+    bool ok = true;
+    std::string why;
+    auto fatom = [&](const mcx_atom& q, int t_event) {
+        FAtom o; o.pad = 0; o.a = q.a; o.d = q.d; o.b = q.b; o.c0 = q.c0; o.c1 = q.c1; o.reg = -1;
+        if (q.col >= 0) {
+            if (q.t_idx != t_event) { ok = false; why = "an event reads the state of another date (unequal swap tenors)"; }
+            o.reg = col_reg[q.col];
+        }
+        return o;
+    };
+    const std::vector<DevEvent>& hev = book->h_events;
+    const std::vector<DevTerm>& hte = book->h_terms;
+    auto devatom_to_mcx = [](const DevAtom& q) { mcx_atom o; o.t_idx = q.t_idx; o.col = q.col; o.a = q.a; o.d = q.d; o.b = q.b; o.c0 = q.c0; o.c1 = q.c1; return o; };
+
+    // events bucketed by timeline date, product order preserved
+    std::vector<std::vector<FEvent>> by_date(T);
+    std::vector<FTerm> terms;
+    int n_stateful = 0;
+    int32_t init_state[MCX_FUSED_MAX_STATEFUL] = {0, 0, 0, 0};
+    if ((int)book->h_event_t_idx.size() != book->n_events) MCX_FAIL(h, -2, "mcx_fused_create: internal (event dates missing)");
+    for (int p = 0; p < book->n_products && ok; ++p) {
+        const DevProduct& pr = book->h_products[p];
+        if (pr.ev_end == pr.ev_begin) continue;
+        int sidx = -1;
+        if (pr.n_states > 1) {
+            if (n_stateful >= MCX_FUSED_MAX_STATEFUL) { ok = false; why = "too many exercise products"; break; }
+            sidx = n_stateful;
+            init_state[n_stateful++] = pr.init_state;
+        }
+        for (int q = pr.ev_begin; q < pr.ev_end && ok; ++q) {
+            const DevEvent& e = hev[q];
+            const int t = book->h_event_t_idx[q];
+            if (t < 0 || t >= T) { ok = false; why = "event date out of range"; break; }
+            FEvent fe;
+            memset(&fe, 0, sizeof(fe));
+            fe.kind = e.kind; fe.flags = e.flags; fe.coeff_off = e.coeff_off; fe.row = e.row; fe.ns = pr.netting_set; fe.sidx = sidx;
+            fe.init_state = pr.init_state; fe.strike = e.strike; fe.sign = e.sign;
+            for (int w = 0; w < 4; ++w) fe.aux[w] = e.aux[w];
+            fe.num = fatom(devatom_to_mcx(e.num), t);
+            fe.x = fatom(devatom_to_mcx(e.x), t);
+            fe.term_begin = (int)terms.size();
+            for (int j = e.term_begin; j < e.term_end; ++j) {
+                if (hte[j].den >= 0) { ok = false; why = "a cashflow term carries its own numeraire (unequal swap tenors)"; break; }
+                FTerm ft; ft.w = hte[j].w; ft.atom = fatom(devatom_to_mcx(hte[j].atom), t);
+                terms.push_back(ft);
+            }
+            fe.term_end = (int)terms.size();
+            by_date[t].push_back(fe);
+        }
+    }
+    // metric ops
+    std::vector<std::vector<FMetricOp>> mop_by_date(T);
+    std::vector<int32_t> date_row(T, -1);
+    for (int r = 0; r < d->n_expo_rows; ++r) {
+        const int t = d->row_t_idx[r];
+        if (t < 0 || t >= T) MCX_FAIL(h, -2, "mcx_fused_create: exposure row %d has no timeline date", r);
+        date_row[t] = r;
+    }
+    mcx_fused* f = new mcx_fused();
+    memset(f, 0, sizeof(*f));
+    int n_rec = 0;
+    for (int k = 0; k < MCX_FUSED_MAX_NS; ++k) { f->rec_pv[k] = -1; f->rec_cva[k] = -1; f->lgd[k] = 0.0; }
+    for (int k = 0; k < d->n_netting_sets && ok; ++k) {
+        const mcx_fused_ns_desc& nd = d->ns[k];
+        if (nd.netting_set != k) { ok = false; why = "netting-set descriptors must be in order"; break; }
+        if (d->want_pv) f->rec_pv[k] = n_rec++;
+        int rec_prof = -1;
+        if (nd.want_profiles) { rec_prof = n_rec; n_rec += 2 * nd.n_dates; }
+        if (nd.want_cva) { f->rec_cva[k] = n_rec++; f->lgd[k] = 1.0 - nd.recovery; }
+        for (int m = 0; m < nd.n_dates; ++m) {
+            const int row = nd.row[m];
+            if (row < 0 || row >= d->n_expo_rows) { ok = false; why = "metric row out of range"; break; }
+            const int t = d->row_t_idx[row];
+            FMetricOp mo;
+            memset(&mo, 0, sizeof(mo));
+            mo.ns = k; mo.m = m; mo.threshold = nd.threshold;
+            mo.rec_profile = nd.want_profiles ? rec_prof + 2 * m : -1;
+            mo.has_cva = (nd.want_cva && m < nd.n_dates - 1) ? 1 : 0;
+            mo.surv.reg = -1; mo.cond.reg = -1;
+            if (mo.has_cva) {
+                const int sa = nd.surv_atoms[m], ca = nd.cond_atoms[m];
+                if (sa < 0 || sa >= book->n_atoms || ca < 0 || ca >= book->n_atoms) { ok = false; why = "CVA atom out of range"; break; }
+                mo.surv = fatom(book->h_atoms[sa], t);
+                mo.cond = fatom(book->h_atoms[ca], t);
+            }
+            if (mo.rec_profile >= 0 || mo.has_cva) mop_by_date[t].push_back(mo);
+        }
+    }
+    if (!ok) { delete f; MCX_FAIL(h, MCX_E_NOT_FUSABLE, "not fusable: %s", why.c_str()); }
+    if (n_rec < 1) { delete f; MCX_FAIL(h, MCX_E_NOT_FUSABLE, "not fusable: no reducible metric requested"); }
+    if ((size_t)(n_rec + 8 * n_rec) * sizeof(double) > 96 * 1024) { delete f; MCX_FAIL(h, MCX_E_NOT_FUSABLE, "not fusable: %d records exceed the LDS budget", n_rec); }
+
+    std::vector<FEvent> events;
+    std::vector<FMetricOp> mops;
+    std::vector<int32_t> date_ev(T + 1, 0), date_mop(T + 1, 0);
+    for (int t = 0; t < T; ++t) {
+        date_ev[t] = (int)events.size();
+        events.insert(events.end(), by_date[t].begin(), by_date[t].end());
+        date_mop[t] = (int)mops.size();
+        mops.insert(mops.end(), mop_by_date[t].begin(), mop_by_date[t].end());
+    }
+    date_ev[T] = (int)events.size();
+    date_mop[T] = (int)mops.size();
+
+    f->sim = sim; f->book = book; f->n_rec = n_rec; f->n_ns = d->n_netting_sets; f->n_dates = T; f->n_expo_rows = d->n_expo_rows;
+    f->n_stateful = n_stateful; f->want_pv = d->want_pv;
+    for (int q = 0; q < MCX_FUSED_MAX_STATEFUL; ++q) f->init_state[q] = init_state[q];
+    auto up = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(dst, bytes ? bytes : 8);
+        if (e != hipSuccess) return e;
+        return bytes ? hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
+    };
+    MCX_HIP(h, up((void**)&f->d_terms, terms.data(), sizeof(FTerm) * terms.size()));
+    MCX_HIP(h, up((void**)&f->d_events, events.data(), sizeof(FEvent) * events.size()));
+    MCX_HIP(h, up((void**)&f->d_mops, mops.data(), sizeof(FMetricOp) * mops.size()));
+    MCX_HIP(h, up((void**)&f->d_date_ev, date_ev.data(), sizeof(int32_t) * date_ev.size()));
+    MCX_HIP(h, up((void**)&f->d_date_mop, date_mop.data(), sizeof(int32_t) * date_mop.size()));
+    MCX_HIP(h, up((void**)&f->d_date_row, date_row.data(), sizeof(int32_t) * date_row.size()));
+    f->partial_bytes = sizeof(double) * 4 * (size_t)n_rec * 2048;
+    MCX_HIP(h, hipMalloc(&f->d_partials, f->partial_bytes));
+    MCX_HIP(h, hipMalloc(&f->d_out, sizeof(mcx_acc) * (size_t)n_rec));
+    *out = f;
+    return 0;
+}
+
+extern "C" int mcx_fused_run(mcx_handle* h, const mcx_fused* f, uint64_t seed, uint64_t path_offset, int64_t n_paths,
+                             double* d_paths, int64_t ld, double* d_cfs, double* d_expo, int64_t ld_out,
+                             const double* d_inject_z, const double* d_inject_u, mcx_acc* h_out, void* stream)
+{
+    if (!h || !f || !h_out) return -1;
+    if (n_paths <= 0) { memset(h_out, 0, sizeof(mcx_acc) * (size_t)f->n_rec); return 0; }
+    if ((d_paths || d_inject_z) && ld < n_paths) MCX_FAIL(h, -2, "mcx_fused_run: ld < n_paths");
+    if ((d_cfs || d_expo) && ld_out < n_paths) MCX_FAIL(h, -2, "mcx_fused_run: ld_out < n_paths");
+    if ((size_t)f->n_rec * sizeof(mcx_acc) > h->pinned_bytes) MCX_FAIL(h, -2, "mcx_fused_run: too many records");
+    const mcx_sim_desc& sd = f->sim->desc;
+    if (sd.n_uniform && d_inject_z && !d_inject_u) MCX_FAIL(h, -3, "mcx_fused_run: inject_u required with inject_z under QE");
+    FusedArgs a;
+    memset(&a, 0, sizeof(a));
+    mcx_fill_k1_args(f->sim, seed, path_offset, n_paths, ld > 0 ? ld : n_paths, d_paths, d_inject_z, d_inject_u, &a.k1);
+    a.terms = f->d_terms; a.events = f->d_events; a.mops = f->d_mops; a.date_ev = f->d_date_ev; a.date_mop = f->d_date_mop;
+    a.date_row = f->d_date_row; a.coeffs = f->book->d_coeffs; a.cfs = d_cfs; a.expo = d_expo; a.partials = f->d_partials;
+    a.ld_out = ld_out; a.n_dates = f->n_dates; a.n_basis = f->book->n_basis; a.n_ns = f->n_ns; a.n_rec = f->n_rec;
+    a.n_expo_rows = f->n_expo_rows; a.n_stateful = f->n_stateful;
+    for (int k = 0; k < MCX_FUSED_MAX_NS; ++k) { a.rec_pv[k] = f->rec_pv[k]; a.rec_cva[k] = f->rec_cva[k]; a.lgd[k] = f->lgd[k]; }
+    for (int k = 0; k < MCX_FUSED_MAX_STATEFUL; ++k) a.init_state[k] = f->init_state[k];
+    const int64_t tiles = (n_paths + MCX_BLOCK - 1) / MCX_BLOCK;
+    int grid = (int)std::min<int64_t>(tiles, 2048);
+    // keep the tiles-per-block count integral when possible (equal work per block)
+    if (tiles > 2048) { int per = (int)((tiles + 2047) / 2048); grid = (int)((tiles + per - 1) / per); }
+    const size_t lds = sizeof(double) * (size_t)(f->n_rec + 8 * f->n_rec);
+    hipStream_t s = (hipStream_t)stream;
+    const bool inj = d_inject_z != nullptr;
+    switch (sd.n_slots * 16 + sd.n_z) {
+    case 1 * 16 + 1: launch_kf<1, 1>(a, grid, lds, inj, s); break;
+    case 1 * 16 + 2: launch_kf<1, 2>(a, grid, lds, inj, s); break;
+    case 2 * 16 + 2: launch_kf<2, 2>(a, grid, lds, inj, s); break;
+    case 3 * 16 + 3: launch_kf<3, 3>(a, grid, lds, inj, s); break;
+    case 4 * 16 + 4: launch_kf<4, 4>(a, grid, lds, inj, s); break;
+    default: MCX_FAIL(h, MCX_E_NOT_FUSABLE, "not fusable: (slots=%d, z=%d) has no fused instantiation", sd.n_slots, sd.n_z);
+    }
+    MCX_HIP(h, hipGetLastError());
+    hipLaunchKernelGGL(kf_merge, dim3((f->n_rec + 63) / 64), dim3(64), 0, s, f->d_partials, f->n_rec, grid, f->d_out);
+    MCX_HIP(h, hipGetLastError());
+    MCX_HIP(h, hipMemcpyAsync(h->h_pinned, f->d_out, sizeof(mcx_acc) * (size_t)f->n_rec, hipMemcpyDeviceToHost, s));
+    MCX_HIP(h, hipStreamSynchronize(s));
+    memcpy(h_out, h->h_pinned, sizeof(mcx_acc) * (size_t)f->n_rec);
+    return 0;
+}

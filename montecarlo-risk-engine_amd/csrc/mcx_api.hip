@@ -136,6 +136,10 @@ extern "C" int mcx_book_create(mcx_handle* h, const mcx_book_desc* d, mcx_book**
             }
         }
     }
+    b->h_events = events; b->h_events.resize(d->n_events);
+    b->h_terms = terms; b->h_terms.resize(d->n_terms);
+    b->h_event_t_idx.resize(d->n_events);
+    for (int i = 0; i < d->n_events; ++i) b->h_event_t_idx[i] = d->events[i].t_idx;
     b->expo_needs_memset = false;
     if (d->want_expo)
         for (size_t q = 0; q < (size_t)d->n_netting_sets * d->n_expo_rows; ++q)

@@ -79,6 +79,9 @@ struct mcx_book {
     DevProduct* d_products;
     double* d_coeffs;
     std::vector<mcx_atom> h_atoms;
+    std::vector<DevEvent> h_events;
+    std::vector<DevTerm> h_terms;
+    std::vector<int32_t> h_event_t_idx;
     std::vector<DevProduct> h_products;
     std::vector<uint8_t> ns_has_writer;   // [n_netting_sets * n_expo_rows]
     bool expo_needs_memset;

@@ -61,6 +61,21 @@ class UnsecuredDesc(C.Structure):
                 ("row", C.c_void_p), ("delayed", C.c_void_p)]
 
 
+class FusedNsDesc(C.Structure):
+    _fields_ = [("netting_set", C.c_int32), ("n_dates", C.c_int32), ("want_profiles", C.c_int32), ("want_cva", C.c_int32),
+                ("threshold", C.c_double), ("recovery", C.c_double),
+                ("row", C.c_void_p), ("surv_atoms", C.c_void_p), ("cond_atoms", C.c_void_p)]
+
+
+class FusedDesc(C.Structure):
+    _fields_ = [("n_netting_sets", C.c_int32), ("want_pv", C.c_int32), ("n_expo_rows", C.c_int32), ("reserved", C.c_int32),
+                ("row_t_idx", C.c_void_p), ("ns", C.c_void_p)]
+
+
+E_NOT_FUSABLE = -10
+FUSED_MAX_NS = 4
+
+
 def ptr(a: np.ndarray | None) -> C.c_void_p:
     """host pointer of a C-contiguous numpy array (None -> NULL)"""
     if a is None:

@@ -22,6 +22,7 @@ _EXPORTS = [
     "mcx_sim_create", "mcx_sim_destroy", "mcx_generate_paths",
     "mcx_book_create", "mcx_book_destroy", "mcx_book_set_coeffs", "mcx_eval_book", "mcx_resolve_atoms",
     "mcx_lsm_stats", "mcx_lsm_step",
+    "mcx_fused_create", "mcx_fused_destroy", "mcx_fused_num_records", "mcx_fused_run",
     "mcx_reduce_vector", "mcx_reduce_profiles", "mcx_reduce_cva", "mcx_unsecured", "mcx_select_hist",
 ]
 
@@ -39,6 +40,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.mcx_destroy.restype = None
     lib.mcx_sim_destroy.restype = None
     lib.mcx_book_destroy.restype = None
+    lib.mcx_fused_destroy.restype = None
+    lib.mcx_fused_num_records.argtypes = [C.c_void_p]
     if lib.mcx_abi_version() != _abi.ABI_VERSION:
         raise RuntimeError("libmcx_hip.so ABI version mismatch")
     return lib
@@ -155,6 +158,29 @@ class HipBackend:
         self._check(self.lib.mcx_resolve_atoms(self.h, book.ptr, _abi.ptr(ids), C.c_int32(len(ids)),
                                                _vp(paths.data_ptr()), C.c_int64(n), C.c_int64(n), _vp(out.data_ptr()),
                                                C.c_int64(n), self._stream()), "mcx_resolve_atoms")
+        return out
+
+    # ---- fused pass ----------------------------------------------------------------------------------------------
+    def fused_create(self, sim, book, plan):
+        """returns None when the book is not fusable (the caller then runs K1/K2/K4 separately)"""
+        out = C.c_void_p()
+        rc = self.lib.mcx_fused_create(self.h, sim.ptr, book.ptr, C.byref(plan.desc), C.byref(out))
+        if rc == _abi.E_NOT_FUSABLE:
+            self.not_fusable_reason = self.lib.mcx_last_error(self.h).decode()
+            return None
+        self._check(rc, "mcx_fused_create")
+        assert self.lib.mcx_fused_num_records(out) == plan.n_records
+        f = _Owned(out, self.lib.mcx_fused_destroy, plan)
+        f.sim, f.book = sim, book
+        return f
+
+    def fused_run(self, fused, seed: int, path_offset: int, n_paths: int, paths=None, cfs=None, expo=None,
+                  inject_z=None, inject_u=None) -> np.ndarray:
+        out = np.zeros(fused.plan.n_records, dtype=_abi.ACC_DTYPE)
+        dp = lambda t: _vp(t.data_ptr() if t is not None else 0)
+        self._check(self.lib.mcx_fused_run(
+            self.h, fused.ptr, C.c_uint64(seed), C.c_uint64(path_offset), C.c_int64(n_paths), dp(paths), C.c_int64(n_paths),
+            dp(cfs), dp(expo), C.c_int64(n_paths), dp(inject_z), dp(inject_u), _abi.ptr(out), self._stream()), "mcx_fused_run")
         return out
 
     # ---- K3 ------------------------------------------------------------------------------------------------------

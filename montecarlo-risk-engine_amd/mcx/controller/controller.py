@@ -28,7 +28,7 @@ from ..metrics.risk_metrics import PathwisePrimitive, RiskMetrics
 from ..models.model import Model
 from ..models.model_config import ModelConfig
 from ..parallel import Shard
-from ..plan import BookCompiler, BookPlan, SimPlan, UnsecuredSpec, solve_normal_equations
+from ..plan import BookCompiler, BookPlan, FusedPlan, SimPlan, UnsecuredSpec, solve_normal_equations
 from ..products.netting_set import NettingSet
 from ..products.product import Product
 from ..request_interface.request_interface import RequestInterface
@@ -95,6 +95,8 @@ class SimulationController:
         self.use_mfma = use_mfma
         # the reference accumulates LSM cashflows in a float32 cache (controller.py:312-330); reproduce it for parity
         self.reference_float32_cf_cache = True
+        self.allow_fused = True      # one-launch main pass (csrc/kf_fused.hip) when the book is fusable
+        self.materialize = False     # also write paths / cashflows / exposures in the fused pass (inspection, tests)
         self._backend = backend
         for i, p in enumerate(products):
             p.product_id = i
@@ -370,7 +372,7 @@ class SimulationController:
         return _key_to_double(prefix)
 
     def _evaluate_netting_set(self, shard: Shard, ns_i: int, ns: NettingSet, cfs, expo, paths, has_pathwise: bool,
-                              analytical_acc: list[float]):
+                              analytical_acc: list[float], fr: dict | None = None):
         be, rm = self.backend, self.risk_metrics
         n_total = self.num_paths_mainsim
         want_expo = rm.requires_exposure_profiles()
@@ -379,8 +381,8 @@ class SimulationController:
         if want_expo:
             delayed = self.netting_set_delayed_exposure_indices[ns_i].numpy() if ns.is_collateralized() else None
             unsec = UnsecuredSpec(self.metric_exposure_indices.numpy(), delayed, ns.threshold, ns.is_collateralized())
-            expo_ns = expo[ns_i]
-        prof = None
+            expo_ns = expo[ns_i] if expo is not None else None
+        prof = fr.get("prof") if fr else None
 
         def profiles():
             nonlocal prof
@@ -388,6 +390,11 @@ class SimulationController:
                 local = be.reduce_profiles(unsec, expo_ns).view(np.float64).reshape(unsec.n_dates, 2, 4)
                 prof = shard.all_gather_np(local)          # [world][E][2][4]
             return prof
+
+        def pv_records():
+            if fr and fr.get("pv") is not None:
+                return fr["pv"]
+            return shard.all_gather_np(be.reduce_vector(cfs[ns_i]).view(np.float64))
 
         out = []
         for m_i, metric in enumerate(rm.metrics):
@@ -399,14 +406,14 @@ class SimulationController:
             if mt == MetricType.PV and metric.evaluation_type == Metric.EvaluationType.ANALYTICAL:
                 val, err = 0.0, 0.0
                 if has_pathwise:
-                    val, err = mean_and_error(shard.all_gather_np(be.reduce_vector(cfs[ns_i]).view(np.float64)))
+                    val, err = mean_and_error(pv_records())
                 out.append([(analytical_acc[m_i] + val, err)])
                 continue
             if not metric._native:
                 out.append(self._evaluate_plugin_metric(metric, ns, unsec, expo_ns, cfs, ns_i, paths))
                 continue
             if mt == MetricType.PV:
-                out.append([mean_and_error(shard.all_gather_np(be.reduce_vector(cfs[ns_i]).view(np.float64)))])
+                out.append([mean_and_error(pv_records())])
             elif mt == MetricType.EPE:
                 out.append([mean_and_error(profiles()[:, m, 0]) for m in range(unsec.n_dates)])
             elif mt == MetricType.ENE:
@@ -418,9 +425,12 @@ class SimulationController:
                 err = float(np.std(ee, ddof=1) / math.sqrt(len(ee))) if len(ee) > 1 else float("nan")
                 out.append([(float(ee.mean()), err)])
             elif mt == MetricType.CVA:
-                surv, cond = self._cva_atoms[m_i]
-                rec = be.reduce_cva(self.book, unsec, surv, cond, metric.recovery_rate, expo_ns, paths)
-                out.append([mean_and_error(shard.all_gather_np(rec.view(np.float64)))])
+                if fr and fr.get("cva") is not None and fr.get("cva_metric") == m_i:
+                    out.append([mean_and_error(fr["cva"])])
+                else:
+                    surv, cond = self._cva_atoms[m_i]
+                    rec = be.reduce_cva(self.book, unsec, surv, cond, metric.recovery_rate, expo_ns, paths)
+                    out.append([mean_and_error(shard.all_gather_np(rec.view(np.float64)))])
             elif mt == MetricType.PFE:
                 q = metric.q_index(n_total)
                 edge = q == 0 or q == n_total - 1
@@ -469,12 +479,72 @@ class SimulationController:
                                              plan=self.sim_plan, sim=self._sim)
         if "main" in self._inject:
             self._main_engine.inject_z, self._main_engine.inject_u = self._inject["main"]
+        self._fused = self._build_fused() if (self.allow_fused and self._mc_products) else None
         be.synchronize()
+
+    def _build_fused(self):
+        """FusedPlan for the one-launch main pass, or None when some requested metric needs the separate kernels"""
+        rm = self.risk_metrics
+        if len(self.netting_sets) > _abi.FUSED_MAX_NS or any(ns.is_collateralized() for ns in self.netting_sets):
+            return None
+        if not all(m._native for m in rm.metrics):
+            return None
+        want_expo = rm.requires_exposure_profiles()
+        kinds = {m.metric_type for m in rm.metrics}
+        want_prof = bool(kinds & {MetricType.EPE, MetricType.ENE, MetricType.CE, MetricType.EEPE})
+        self._fused_needs_expo = MetricType.PFE in kinds
+        specs, self._fused_cva_metric = [], []
+        for ns_i, ns in enumerate(self.netting_sets):
+            cva = [m_i for m_i, m in enumerate(rm.metrics) if m.metric_type == MetricType.CVA
+                   and not (ns.counterparty_id is not None and m.counterparty_id != ns.counterparty_id)]
+            if len(cva) > 1:
+                return None
+            sp = dict(rows=self.metric_exposure_indices.numpy() if want_expo else np.zeros(0, dtype=np.int32),
+                      want_profiles=want_prof and want_expo, threshold=ns.threshold, surv=None, cond=None, recovery=0.0)
+            if cva:
+                sp["surv"], sp["cond"] = self._cva_atoms[cva[0]]
+                sp["recovery"] = rm.metrics[cva[0]].recovery_rate
+            self._fused_cva_metric.append(cva[0] if cva else None)
+            specs.append(sp)
+        tl = {float(t): i for i, t in enumerate(self.simulation_timeline)}
+        row_t = [tl[float(t)] for t in self.exposure_timeline] if want_expo else []
+        plan = FusedPlan(specs, rm.any_pv, row_t)
+        if plan.n_records == 0:
+            return None
+        return self.backend.fused_create(self._sim, self.book, plan)
+
+    def _fused_pass(self, paths_out=None):
+        be, f, eng = self.backend, self._fused, self._main_engine
+        n = eng.num_paths
+        need_expo = self._fused_needs_expo or self.materialize
+        paths = (paths_out if paths_out is not None else be.empty(self.sim_plan.n_dates, self.sim_plan.n_state, n)) \
+            if (self.materialize or paths_out is not None) else None
+        bp = self.book_plan
+        expo = be.empty(bp.n_netting_sets, bp.n_expo_rows, n) if (need_expo and bp.desc.want_expo) else None
+        cfs = be.empty(bp.n_netting_sets, n) if (self.materialize and bp.desc.want_cfs) else None
+        rec = be.fused_run(f, eng.seed, eng.path_offset, n, paths=paths, cfs=cfs, expo=expo,
+                           inject_z=eng.inject_z, inject_u=eng.inject_u)
+        g = self._shard.all_gather_np(rec.view(np.float64).reshape(-1, 4))        # [world][n_rec][4]
+        fused_records = []
+        for ns_i, lay in enumerate(f.plan.layout):
+            nd = lay["n_dates"]
+            fr = dict(pv=None, prof=None, cva=None, cva_metric=self._fused_cva_metric[ns_i])
+            if lay["pv"] is not None:
+                fr["pv"] = g[:, lay["pv"]]
+            if lay["prof"] is not None:
+                fr["prof"] = g[:, lay["prof"]:lay["prof"] + 2 * nd].reshape(g.shape[0], nd, 2, 4)
+            if lay["cva"] is not None:
+                fr["cva"] = g[:, lay["cva"]]
+            fused_records.append(fr)
+        self.last_state.update(paths=paths, cfs=cfs, expo=expo)
+        return self._evaluate_all(self._shard, cfs, expo, paths, fused_records)
 
     def main_pass(self, paths_out=None):
         """ONE pass of the hot path over this rank's shard of the main-simulation paths: K1 path generation, K2 book
         evaluation, K4/K5 reductions (+ the accumulator collectives). Returns the nested metric results."""
         be = self.backend
+        if self._fused is not None:
+            return self._fused_pass(paths_out)
         paths = self._main_engine.generate_paths_native(out=paths_out)
         cfs, expo = be.eval_book(self.book, paths) if self._mc_products else (None, None)
         self.last_state.update(paths=paths, cfs=cfs, expo=expo)
@@ -488,6 +558,15 @@ class SimulationController:
         be = self.backend
         self.prepare()
         t1 = time.perf_counter()
+        if self._fused is not None:
+            results = self._fused_pass()
+            be.synchronize()
+            t4 = time.perf_counter()
+            self.timings = dict(preprocessing=t1 - t0, path_generation=t4 - t1, request_resolution=0.0, valuation=0.0,
+                                metrics=0.0, total=t4 - t0, fused=True)
+            logger.info("Simulation completed for %d netting set(s) and %d product(s): preprocessing=%.6fs "
+                        "fused_main_pass=%.6fs total=%.6fs", len(self.netting_sets), len(self.products), t1 - t0, t4 - t1, t4 - t0)
+            return self._package(results, [], [])
         paths = self._main_engine.generate_paths_native()
         be.synchronize()
         t2 = time.perf_counter()
@@ -512,7 +591,7 @@ class SimulationController:
         self.book_plan = BookPlan(self._comp, *self._plan_args)
         self.book = self.backend.book_create(self.book_plan)
 
-    def _evaluate_all(self, shard, cfs, expo, paths):
+    def _evaluate_all(self, shard, cfs, expo, paths, fused_records=None):
         analytical = [[0.0 for _ in self.risk_metrics.metrics] for _ in self.netting_sets]
         has_pathwise = [False] * len(self.netting_sets)
         for p_i, p in enumerate(self.products):
@@ -522,7 +601,8 @@ class SimulationController:
                     analytical[ns_i][m_i] += float(m.evaluate_analytically(product=p, model=self.model)[0][0])
             else:
                 has_pathwise[ns_i] = True
-        return [self._evaluate_netting_set(shard, i, ns, cfs, expo, paths, has_pathwise[i], analytical[i])
+        return [self._evaluate_netting_set(shard, i, ns, cfs, expo, paths, has_pathwise[i], analytical[i],
+                                           fused_records[i] if fused_records else None)
                 for i, ns in enumerate(self.netting_sets)]
 
     def _package(self, results, grads, higher):

@@ -203,3 +203,44 @@ def solve_normal_equations(moments: np.ndarray, K: int, S: int, shift: float, sc
         for j in range(k + 1):
             T[j, k] = (scale ** k) * math.comb(k, j) * ((-shift) ** (k - j))
     return (T @ b).T
+
+
+class FusedPlan:
+    """mcx_fused_desc: which accumulator records the fused pass produces, per netting set, and where they sit in the
+    flat record array: [PV][2*n_dates profiles][CVA] per netting set, in netting-set order."""
+
+    def __init__(self, ns_specs: list[dict], want_pv: bool, row_t_idx):
+        self.row_t_idx = np.ascontiguousarray(row_t_idx, dtype=np.int32)
+        self.specs = ns_specs
+        self.want_pv = bool(want_pv)
+        self._keep = []
+        arr = (_abi.FusedNsDesc * len(ns_specs))()
+        self.layout = []            # per netting set: dict(pv=idx|None, prof=idx|None, cva=idx|None, n_dates)
+        pos = 0
+        for k, sp in enumerate(ns_specs):
+            rows = np.ascontiguousarray(sp["rows"], dtype=np.int32)
+            surv = np.ascontiguousarray(sp["surv"], dtype=np.int32) if sp.get("surv") is not None else None
+            cond = np.ascontiguousarray(sp["cond"], dtype=np.int32) if sp.get("cond") is not None else None
+            self._keep += [rows, surv, cond]
+            d = arr[k]
+            d.netting_set, d.n_dates = k, len(rows)
+            d.want_profiles, d.want_cva = int(sp["want_profiles"]), int(surv is not None)
+            d.threshold, d.recovery = float(sp["threshold"]), float(sp.get("recovery", 0.0))
+            d.row, d.surv_atoms, d.cond_atoms = _abi.ptr(rows), _abi.ptr(surv), _abi.ptr(cond)
+            lay = dict(pv=None, prof=None, cva=None, n_dates=len(rows))
+            if self.want_pv:
+                lay["pv"] = pos
+                pos += 1
+            if sp["want_profiles"]:
+                lay["prof"] = pos
+                pos += 2 * len(rows)
+            if surv is not None:
+                lay["cva"] = pos
+                pos += 1
+            self.layout.append(lay)
+        self.n_records = pos
+        self._ns_array = arr
+        d = _abi.FusedDesc()
+        d.n_netting_sets, d.want_pv, d.n_expo_rows = len(ns_specs), int(self.want_pv), len(self.row_t_idx)
+        d.row_t_idx, d.ns = _abi.ptr(self.row_t_idx), C.cast(arr, C.c_void_p)
+        self.desc = d

@@ -170,10 +170,12 @@ def load_golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"))
 
 
-def make_controller(name, backend, inject=True):
+def make_controller(name, backend, inject=True, fused=True):
     build, n_pre, n_main, steps, scheme, diff = CASES[name]
     ns, model, rm = build()
     sc = SimulationController(ns, model, rm, n_main, n_pre, steps, scheme, differentiate=diff, backend=backend)
+    sc.materialize = True
+    sc.allow_fused = fused
     g = load_golden(name)
     if inject:
         def prep(key_z, key_u):

@@ -156,6 +156,33 @@ class OracleBackend:
                                  C.c_int32(shift), C.c_int32(bits), _p(hist))
         return hist
 
+    # the "fused pass" of the oracle is simply the composition of its primitives with the same record layout
+    def fused_create(self, sim, book, plan):
+        f = _Obj(plan)
+        f.sim, f.book = sim, book
+        return f
+
+    def fused_run(self, fused, seed, path_offset, n_paths, paths=None, cfs=None, expo=None, inject_z=None, inject_u=None):
+        from mcx.plan import UnsecuredSpec
+        plan = fused.plan
+        p = self.generate_paths(fused.sim, seed, path_offset, n_paths, inject_z, inject_u, out=paths)
+        c, e = self.eval_book(fused.book, p)
+        if cfs is not None and c is not None:
+            cfs.copy_(c)
+        if expo is not None and e is not None:
+            expo.copy_(e)
+        out = np.zeros(plan.n_records, dtype=self._abi.ACC_DTYPE)
+        for k, (lay, sp) in enumerate(zip(plan.layout, plan.specs)):
+            unsec = UnsecuredSpec(sp["rows"], None, sp["threshold"], False)
+            nd = len(sp["rows"])
+            if lay["pv"] is not None:
+                out[lay["pv"]] = self.reduce_vector(c[k])[0]
+            if lay["prof"] is not None:
+                out[lay["prof"]:lay["prof"] + 2 * nd] = self.reduce_profiles(unsec, e[k]).reshape(-1)
+            if lay["cva"] is not None:
+                out[lay["cva"]] = self.reduce_cva(fused.book, unsec, sp["surv"], sp["cond"], sp["recovery"], e[k], p)[0]
+        return out
+
     # straight sort-based restatement of pfe_metric.py:49-73 (checks the radix select)
     def pfe_sort(self, unsec, expo_ns, q_index):
         n = expo_ns.shape[1]

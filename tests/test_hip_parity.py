@@ -44,17 +44,19 @@ def _check_against_golden(sc, res, g, name):
             assert np.allclose(ours[:, 1], ref[:, 1], rtol=1e-6, atol=1e-12), (name, metric.get_name(), ours[:, 1], ref[:, 1])
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "unfused"])
 @pytest.mark.parametrize("name", NON_AAD)
-def test_inject_z_against_reference(name, hip):
-    sc, g = cases.make_controller(name, hip)
+def test_inject_z_against_reference(name, fused, hip):
+    sc, g = cases.make_controller(name, hip, fused=fused)
     res = sc.run_simulation()
     _check_against_golden(sc, res, g, name)
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "unfused"])
 @pytest.mark.parametrize("name", NON_AAD)
-def test_philox_gpu_vs_oracle(name, hip, oracle):
-    sc_g, _ = cases.make_controller(name, hip, inject=False)
-    sc_c, _ = cases.make_controller(name, oracle, inject=False)
+def test_philox_gpu_vs_oracle(name, fused, hip, oracle):
+    sc_g, _ = cases.make_controller(name, hip, inject=False, fused=fused)
+    sc_c, _ = cases.make_controller(name, oracle, inject=False, fused=False)
     rg, rc = sc_g.run_simulation(), sc_c.run_simulation()
     pg = sc_g.last_state["paths"].cpu().numpy()
     pc = sc_c.last_state["paths"].numpy()
@@ -126,3 +128,22 @@ def test_statistical_anchor_bs_call(hip):
     exact = float(ns[0].products[0].compute_pv_analytically(model))
     assert abs(pv - exact) < 4 * err, (pv, exact, err)
     assert 0.02 < err < 0.05
+
+
+def test_fused_pass_is_used_and_lean(hip):
+    """config-3-like book: the fused kernel is selected and, without `materialize`, no path/exposure tensor is created"""
+    sc, _ = cases.make_controller("irs_cva", hip, inject=False)
+    sc.materialize = False
+    res = sc.run_simulation()
+    assert sc._fused is not None and sc.timings.get("fused")
+    assert sc.last_state["paths"] is None and sc.last_state["expo"] is None
+    sc2, _ = cases.make_controller("irs_cva", hip, inject=False, fused=False)
+    res2 = sc2.run_simulation()
+    a, b = res.results[0][0][0], res2.results[0][0][0]
+    assert np.isclose(a[0], b[0], rtol=1e-10) and np.isclose(a[1], b[1], rtol=1e-8)
+
+
+def test_unfusable_books_fall_back(hip):
+    sc, _ = cases.make_controller("netting", hip)          # collateralised netting set + unequal swap tenors
+    sc.run_simulation()
+    assert sc._fused is None
