@@ -80,7 +80,8 @@ def main():
     ap.add_argument("--paths", type=int, default=1 << 20, help="main-simulation paths PER GPU")
     ap.add_argument("--presim", type=int, default=131072, help="pre-simulation (LSM) paths PER GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--unfused", action="store_true", help="run K1, K2, K4 as separate launches (materialised tensors)")
+    ap.add_argument("--unfused", action="store_true", help="force K1, K2, K4 as separate launches (materialised tensors)")
+    ap.add_argument("--fused", action="store_true", help="force the single fused launch")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -110,8 +111,28 @@ def main():
         torch.cuda.synchronize()
 
     res = None
-    if args.unfused:
-        sc._fused = None
+    # two execution plans exist for the main pass (one fused launch / K1+K2+K4 launches); time both once, keep the faster
+    plan_ms = {}
+    fused_obj = sc._fused
+    for name, obj in (("fused", fused_obj), ("unfused", None)):
+        if name == "fused" and (obj is None or args.unfused):
+            continue
+        if name == "unfused" and args.fused:
+            continue
+        sc._fused = obj
+        sc.main_pass(paths_buf if obj is None else None)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            sc.main_pass(paths_buf if obj is None else None)
+        barrier()
+        plan_ms[name] = (time.perf_counter() - t0) / 2 * 1e3
+    best = min(plan_ms, key=plan_ms.get)
+    if world > 1:      # all ranks must agree
+        flag = torch.tensor([1.0 if best == "fused" else 0.0], device="cuda")
+        dist.broadcast(flag, 0)
+        best = "fused" if flag.item() > 0.5 else "unfused"
+    sc._fused = fused_obj if best == "fused" else None
     for _ in range(args.warmup):
         res = sc.main_pass(paths_buf if sc._fused is None else None)
     # per-kernel device time of the dominant kernel (K1) with HIP events on the launch stream
@@ -152,7 +173,8 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "Vasicek+CIR++ (rho=0.5) payer IRS CVA, Euler, 51 dates x 5 sub-steps (SURVEY §8d config 3)",
                        "paths_per_gpu": n_local, "steps_per_path": S, "state_dim": D, "stored_dates": T,
-                       "exposure_dates": E, "presim_paths_per_gpu": args.presim, "parallelism": f"paths x{world}"},
+                       "exposure_dates": E, "presim_paths_per_gpu": args.presim, "parallelism": f"paths x{world}",
+                       "execution_plan": "fused" if fused else "unfused", "plan_probe_ms": plan_ms},
             "roofline": {"bound": "hbm", "kernel": "kf_fused<2,2> (K1+K2+K4 in one launch)" if fused else "k1_paths<2,2> (Philox+Box-Muller+Cholesky+Euler)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel_ms": k1_ms, "algorithmic_bytes_per_launch": k1_bytes,

@@ -20,80 +20,28 @@
 namespace {
 
 
-template <int NSLOT, int NZ, bool INJECT>
+template <int NSLOT, int NZ, bool INJECT, int SIG>
 __global__ __launch_bounds__(MCX_BLOCK) void k1_paths(const K1Args a)
 {
     const int64_t i = (int64_t)blockIdx.x * MCX_BLOCK + threadIdx.x;
     if (i >= a.n) return;
-    const int64_t ld = a.ld;
-    const int D = a.n_state;
-    double* __restrict__ out = a.paths + i;
-
-    double st[NSLOT][2];
-#pragma unroll
-    for (int s = 0; s < NSLOT; ++s) {
-        st[s][0] = a.init_state[a.slots[s].state_off];
-        st[s][1] = (a.slots[s].kind == MCX_MODEL_BS) ? 0.0 : a.init_state[a.slots[s].state_off + 1];
-    }
-    auto store = [&](int t) {
-#pragma unroll
-        for (int s = 0; s < NSLOT; ++s) {
-            const int c = a.slots[s].state_off;
-            out[((int64_t)t * D + c) * ld] = st[s][0];
-            if (a.slots[s].kind != MCX_MODEL_BS) out[((int64_t)t * D + c + 1) * ld] = st[s][1];
-        }
-    };
-    for (int t = 0; t < a.n_initial_store; ++t) store(t);
-
+    double reg[2 * NSLOT];
+    sim_init_state<NSLOT, SIG>(a, reg);
+    for (int t = 0; t < a.n_initial_store; ++t) sim_store_state<NSLOT, SIG>(a, t, i, reg);
     const uint64_t path = a.path_offset + (uint64_t)i;
     for (int k = 0; k < a.n_steps; ++k) {
-        const mcx_step sp = a.steps[k];                    // wave-uniform -> scalar loads
-        double z[NZ], zc[NZ], u = 0.0;
-        if (INJECT) {
-#pragma unroll
-            for (int j = 0; j < NZ; ++j) z[j] = a.inject_z[((int64_t)k * NZ + j) * ld + i];
-            if (a.n_uniform) u = a.inject_u[(int64_t)k * ld + i];
-        } else {
-            double ua;
-#pragma unroll
-            for (int q = 0; q < (NZ + 1) / 2; ++q) {
-                double z0, z1;
-                draw_pair(a.seed, path, (uint32_t)k, (uint32_t)q, ua, z0, z1);
-                z[2 * q] = z0;
-                if (2 * q + 1 < NZ) z[2 * q + 1] = z1;
-            }
-            if (a.n_uniform) {
-                double z0, z1;
-                draw_pair(a.seed, path, (uint32_t)k, (uint32_t)((NZ + 1) / 2), u, z0, z1);
-            }
-        }
-        const double* __restrict__ L = a.chol + (int64_t)sp.chol_idx * NZ * NZ;     // model.py:48  z @ chol.T
-#pragma unroll
-        for (int r = 0; r < NZ; ++r) {
-            double acc = 0.0;
-#pragma unroll
-            for (int c = 0; c <= r; ++c) acc += L[r * NZ + c] * z[c];
-            zc[r] = acc;
-        }
-        const double* __restrict__ ax = a.aux + (int64_t)k * NSLOT * MCX_AUX;
-#pragma unroll
-        for (int s = 0; s < NSLOT; ++s) {
-            // ModelConfig only hosts sub-models with simulation_dim == 1 (model_config.py:106-107); Heston runs alone
-            const double zc0 = (NSLOT == 1) ? zc[0] : zc[s < NZ ? s : 0];
-            const double zc1 = (NSLOT == 1 && NZ > 1) ? zc[NZ > 1 ? 1 : 0] : 0.0;
-            step_slot(a.slots[s], a.scheme, a.flags | a.slots[s].flags, sp.dt, sp.sqrt_dt, ax + s * MCX_AUX,
-                      st[s][0], st[s][1], zc0, zc1, u);
-        }
-        if (sp.store_idx >= 0) store(sp.store_idx);
+        sim_substep<NSLOT, NZ, INJECT, SIG>(a, k, path, i, reg);
+        const int st = ldk(&a.steps[k].store_idx);
+        if (st >= 0) sim_store_state<NSLOT, SIG>(a, st, i, reg);
     }
 }
 
-template <int NSLOT, int NZ>
+template <int NSLOT, int NZ, int SIG>
 int launch_k1(const K1Args& a, bool inject, hipStream_t s)
 {
     const int grid = (int)((a.n + MCX_BLOCK - 1) / MCX_BLOCK);
-    if (inject) hipLaunchKernelGGL((k1_paths<NSLOT, NZ, true>), dim3(grid), dim3(MCX_BLOCK), 0, s, a);
-    else hipLaunchKernelGGL((k1_paths<NSLOT, NZ, false>), dim3(grid), dim3(MCX_BLOCK), 0, s, a);
+    if (inject) hipLaunchKernelGGL((k1_paths<NSLOT, NZ, true, SIG>), dim3(grid), dim3(MCX_BLOCK), 0, s, a);
+    else hipLaunchKernelGGL((k1_paths<NSLOT, NZ, false, SIG>), dim3(grid), dim3(MCX_BLOCK), 0, s, a);
     return 0;
 }
 
@@ -163,18 +111,28 @@ extern "C" int mcx_generate_paths(mcx_handle* h, const mcx_sim* sim, uint64_t se
     mcx_fill_k1_args(sim, seed, path_offset, n_paths, ld, d_paths, d_inject_z, d_inject_u, &a);
     hipStream_t s = (hipStream_t)stream;
     const bool inj = d_inject_z != nullptr;
-    const int key = d.n_slots * 16 + d.n_z;
-    switch (key) {
-    case 1 * 16 + 1: launch_k1<1, 1>(a, inj, s); break;
-    case 1 * 16 + 2: launch_k1<1, 2>(a, inj, s); break;
-    case 2 * 16 + 2: launch_k1<2, 2>(a, inj, s); break;
-    case 3 * 16 + 3: launch_k1<3, 3>(a, inj, s); break;
-    case 4 * 16 + 4: launch_k1<4, 4>(a, inj, s); break;
-    case 5 * 16 + 5: launch_k1<5, 5>(a, inj, s); break;
-    case 6 * 16 + 6: launch_k1<6, 6>(a, inj, s); break;
-    case 7 * 16 + 7: launch_k1<7, 7>(a, inj, s); break;
-    case 8 * 16 + 8: launch_k1<8, 8>(a, inj, s); break;
-    default: MCX_FAIL(h, -4, "mcx_generate_paths: unsupported (slots=%d, z=%d)", d.n_slots, d.n_z);
+    switch (mcx_sim_signature(d)) {       // specialised (compile-time model kinds) instantiations of the hot configurations
+    case SIG_VAS_CIR_E: launch_k1<2, 2, SIG_VAS_CIR_E>(a, inj, s); break;
+    case SIG_BS_A: launch_k1<1, 1, SIG_BS_A>(a, inj, s); break;
+    case SIG_BS_E: launch_k1<1, 1, SIG_BS_E>(a, inj, s); break;
+    case SIG_HESTON_QE: launch_k1<1, 2, SIG_HESTON_QE>(a, inj, s); break;
+    case SIG_HESTON_E: launch_k1<1, 2, SIG_HESTON_E>(a, inj, s); break;
+    case SIG_VAS_E: launch_k1<1, 1, SIG_VAS_E>(a, inj, s); break;
+    case SIG_VAS_A: launch_k1<1, 1, SIG_VAS_A>(a, inj, s); break;
+    case SIG_BS_VAS_CIRDET_E: launch_k1<3, 3, SIG_BS_VAS_CIRDET_E>(a, inj, s); break;
+    default:
+        switch (d.n_slots * 16 + d.n_z) {
+        case 1 * 16 + 1: launch_k1<1, 1, SIG_GENERIC>(a, inj, s); break;
+        case 1 * 16 + 2: launch_k1<1, 2, SIG_GENERIC>(a, inj, s); break;
+        case 2 * 16 + 2: launch_k1<2, 2, SIG_GENERIC>(a, inj, s); break;
+        case 3 * 16 + 3: launch_k1<3, 3, SIG_GENERIC>(a, inj, s); break;
+        case 4 * 16 + 4: launch_k1<4, 4, SIG_GENERIC>(a, inj, s); break;
+        case 5 * 16 + 5: launch_k1<5, 5, SIG_GENERIC>(a, inj, s); break;
+        case 6 * 16 + 6: launch_k1<6, 6, SIG_GENERIC>(a, inj, s); break;
+        case 7 * 16 + 7: launch_k1<7, 7, SIG_GENERIC>(a, inj, s); break;
+        case 8 * 16 + 8: launch_k1<8, 8, SIG_GENERIC>(a, inj, s); break;
+        default: MCX_FAIL(h, -4, "mcx_generate_paths: unsupported (slots=%d, z=%d)", d.n_slots, d.n_z);
+        }
     }
     MCX_HIP(h, hipGetLastError());
     return 0;

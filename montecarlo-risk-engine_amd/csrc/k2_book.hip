@@ -42,9 +42,10 @@ __device__ __forceinline__ double dev_cash_event(const DevEvent& e, const DevTer
     const double num = dev_atom(e.num, paths, D, ld, i);
     double common = 0.0, own = 0.0;
     for (int j = e.term_begin; j < e.term_end; ++j) {
-        const double v = terms[j].w * dev_atom(terms[j].atom, paths, D, ld, i);
-        if (terms[j].den < 0) common += v;
-        else own += v / dev_atom(atoms[terms[j].den], paths, D, ld, i);
+        const DevTerm tm = ldk_struct(&terms[j]);
+        const double v = tm.w * dev_atom(tm.atom, paths, D, ld, i);
+        if (tm.den < 0) common += v;
+        else own += v / dev_atom(ldk_struct(&atoms[tm.den]), paths, D, ld, i);
     }
     if (e.kind == MCX_EV_CASHFLOW) return common / num + own;
     const double imm = fmax(e.sign * (common - e.strike), 0.0);
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(MCX_BLOCK) void k2_eval_book(const K2Args a)
     int cur_ns = -1;
     double acc_ns = 0.0;
     for (int p = 0; p < a.n_products; ++p) {
-        const DevProduct pr = a.products[p];
+        const DevProduct pr = ldk_struct(&a.products[p]);
         if (pr.ev_end == pr.ev_begin) continue;              // analytically valued product: no Monte-Carlo events
         if (pr.netting_set != cur_ns) {
             if (cur_ns >= 0 && a.want_cfs) a.cfs[(int64_t)cur_ns * a.ld_out + i] = acc_ns;
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(MCX_BLOCK) void k2_eval_book(const K2Args a)
         int s = pr.init_state;
         double acc = 0.0;
         for (int q = pr.ev_begin; q < pr.ev_end; ++q) {
-            const DevEvent& e = a.events[q];
+            const DevEvent e = ldk_struct(&a.events[q]);
             if (e.kind <= MCX_EV_EXERCISE) {
                 acc += dev_cash_event(e, a.terms, a.atoms, a.coeffs, K, a.paths, D, ld, i, s);
             } else {
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(MCX_BLOCK) void k2_resolve(const DevAtom* __restric
     const int64_t i = (int64_t)blockIdx.x * MCX_BLOCK + threadIdx.x;
     if (i >= n) return;
     const int q = blockIdx.y;
-    out[(int64_t)q * ld_out + i] = dev_atom(atoms[ids[q]], paths, D, ld, i);
+    out[(int64_t)q * ld_out + i] = dev_atom(ldk_struct(&atoms[ldk(ids + q)]), paths, D, ld, i);
 }
 
 }  // namespace

@@ -41,9 +41,10 @@ __device__ __forceinline__ double k3_cash_event(const DevEvent& e, const K3Args&
     const double num = dev_atom(e.num, a.paths, D, a.ld, i);
     double common = 0.0, own = 0.0;
     for (int j = e.term_begin; j < e.term_end; ++j) {
-        const double v = a.terms[j].w * dev_atom(a.terms[j].atom, a.paths, D, a.ld, i);
-        if (a.terms[j].den < 0) common += v;
-        else own += v / dev_atom(a.atoms[a.terms[j].den], a.paths, D, a.ld, i);
+        const DevTerm tm = ldk_struct(&a.terms[j]);
+        const double v = tm.w * dev_atom(tm.atom, a.paths, D, a.ld, i);
+        if (tm.den < 0) common += v;
+        else own += v / dev_atom(ldk_struct(&a.atoms[tm.den]), a.paths, D, a.ld, i);
     }
     if (e.kind == MCX_EV_CASHFLOW) return common / num + own;
     const double imm = fmax(e.sign * (common - e.strike), 0.0);
@@ -70,7 +71,7 @@ __device__ __forceinline__ void k3_roll(const K3Args& a, int64_t i, double (&y)[
             int s = s0;
             double step_value = 0.0;
             for (int q = a.roll_begin; q < a.roll_end; ++q) {               // controller.py:333-341
-                step_value += k3_cash_event(a.events[q], a, D, i, s);
+                step_value += k3_cash_event(ldk_struct(&a.events[q]), a, D, i, s);
                 if (a.f32_cache) step_value = (double)(float)step_value;     // float32 cf_cache quirk (controller.py:312-330)
             }
             double tail = w[0];
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(MCX_BLOCK) void k3_minmax(const DevAtom* __restrict
                                                        double* __restrict__ partials)
 {
     const int q = blockIdx.y;
-    const DevAtom at = atoms[ids[q]];
+    const DevAtom at = ldk_struct(&atoms[ldk(ids + q)]);
     double lo = INFINITY, hi = -INFINITY;
     for (int64_t i = (int64_t)blockIdx.x * MCX_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * MCX_BLOCK) {
         const double x = dev_atom(at, paths, D, ld, i);

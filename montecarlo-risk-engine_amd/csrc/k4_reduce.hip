@@ -69,8 +69,8 @@ __global__ __launch_bounds__(MCX_BLOCK) void k4_cva_paths(const DevUnsec u, cons
     double acc = 0.0;
     for (int m = 0; m < u.n_dates - 1; ++m) {
         const double e = fmax(dev_unsec(u, expo, ld_expo, m, i), 0.0);
-        const double sp = dev_atom(atoms[surv[m]], paths, D, ld_paths, i);
-        const double cs = dev_atom(atoms[cond[m]], paths, D, ld_paths, i);
+        const double sp = dev_atom(ldk_struct(&atoms[ldk(surv + m)]), paths, D, ld_paths, i);
+        const double cs = dev_atom(ldk_struct(&atoms[ldk(cond + m)]), paths, D, ld_paths, i);
         acc = fma(e, sp * (1.0 - cs), acc);
     }
     out[i] = acc * lgd;

@@ -39,20 +39,19 @@ struct FMetricOp {             // one (netting set, metric date) pair, executed 
     FAtom surv, cond;
 };
 
+struct ChunkHeader { int32_t n_ev, n_mop, n_terms, bytes; };
+
 struct FusedArgs {
     K1Args k1;
-    const FTerm* __restrict__ terms;
-    const FEvent* __restrict__ events;
-    const FMetricOp* __restrict__ mops;
-    const int32_t* __restrict__ date_ev;      // [n_dates+1] event range per timeline date
-    const int32_t* __restrict__ date_mop;     // [n_dates+1]
+    const unsigned char* __restrict__ prog;   // per-date program chunks (header | events | terms | metric ops)
+    const int32_t* __restrict__ date_off;     // [n_dates+1] byte offset of each date's chunk (16-byte aligned)
     const int32_t* __restrict__ date_row;     // [n_dates] exposure row of this timeline date or -1
     const double* __restrict__ coeffs;
     double* __restrict__ cfs;                 // nullable [NS][ld_out]
     double* __restrict__ expo;                // nullable [NS][n_expo_rows][ld_out]
     double* __restrict__ partials;            // [gridDim.x][n_rec][4]
     int64_t ld_out;
-    int32_t n_dates, n_basis, n_ns, n_rec, n_expo_rows, n_stateful;
+    int32_t n_dates, n_basis, n_ns, n_rec, n_expo_rows, n_stateful, chunk_cap, pad;
     int32_t rec_pv[MCX_FUSED_MAX_NS];         // record index of the PV record of ns slot k, or -1
     int32_t rec_cva[MCX_FUSED_MAX_NS];
     double lgd[MCX_FUSED_MAX_NS];
@@ -64,7 +63,7 @@ __device__ __forceinline__ double f_atom(const FAtom& a, const double (&reg)[NRE
 {
     double x = 0.0;
 #pragma unroll
-    for (int q = 0; q < NREG; ++q) x = (a.reg == q) ? reg[q] : x;     // wave-uniform select
+    for (int q = 0; q < NREG; ++q) x = (a.reg == q) ? reg[q] : x;
     double v = fma(a.d, x, a.a);
     if (a.b != 0.0) v = fma(a.b, exp(fma(a.c1, x, a.c0)), v);
     return v;
@@ -73,13 +72,14 @@ __device__ __forceinline__ double f_atom(const FAtom& a, const double (&reg)[NRE
 __device__ __forceinline__ double f_poly(const double* __restrict__ c, int K, double x)
 {
     double v = 0.0, xp = 1.0;
+#pragma unroll 1
     for (int k = 0; k < K; ++k) { v = fma(c[k], xp, v); xp *= x; }
     return v;
 }
 
 __device__ __forceinline__ double f_norm_cdf(double x) { return 0.5 * (1.0 + erf(x * 0.70710678118654752440)); }
 
-// LDS layout: shift[n_rec] | acc[4 waves][n_rec][2]
+// LDS record area: shift[n_rec] | acc[4 waves][n_rec][2]
 __device__ __forceinline__ void f_record(double v, bool live, int rec, int n_rec, bool first_tile, double* __restrict__ lds)
 {
     if (first_tile) {                      // block-uniform: the first path the block sees fixes the record's shift
@@ -97,18 +97,166 @@ __device__ __forceinline__ void f_record(double v, bool live, int rec, int n_rec
     }
 }
 
-template <int NSLOT, int NZ, bool INJECT>
-__global__ __launch_bounds__(MCX_BLOCK) void kf_fused(const FusedArgs a)
+// The book's events + metric operations of ONE timeline date for one lane.  The date's program chunk sits in the wave's
+// private LDS slot (`chunk`): all 64 lanes read the same addresses (LDS broadcast, no bank conflicts), so walking the
+// program costs ds_read latency (~64-128 clk) instead of a chain of dependent L2 round trips per record.
+template <int NSLOT, int SIG, int NNS, int NSTA>
+__device__ __forceinline__ void kf_on_date(const FusedArgs& a, int t, int64_t i, bool live, bool first_tile, double* __restrict__ lds,
+                                           const unsigned char* __restrict__ chunk, const double (&reg)[2 * NSLOT],
+                                           double (&cfs)[NNS], double (&cva)[NNS], int (&est)[NSTA])
 {
     constexpr int NREG = 2 * NSLOT;
+    const K1Args& k = a.k1;
+    const int n_rec = a.n_rec;
+    if (k.paths && live) sim_store_state<NSLOT, SIG>(k, t, i, reg);
+    const ChunkHeader hd = *(const ChunkHeader*)chunk;
+    const FEvent* __restrict__ evs = (const FEvent*)(chunk + sizeof(ChunkHeader));
+    const FTerm* __restrict__ terms = (const FTerm*)(evs + hd.n_ev);
+    const FMetricOp* __restrict__ mops = (const FMetricOp*)(terms + hd.n_terms);
+    double e_ns[NNS];
+#pragma unroll
+    for (int q = 0; q < NNS; ++q) e_ns[q] = 0.0;
+    double inv_num = 0.0;
+#pragma unroll 1
+    for (int q = 0; q < hd.n_ev; ++q) {
+        const FEvent& e = evs[q];
+        if (!(e.flags & 2)) inv_num = 1.0 / f_atom<NREG>(e.num, reg);       // flag bit1: same numeraire as the previous event
+        __builtin_amdgcn_sched_barrier(0);   // keep the record reads of each phase close to their use (VGPR live ranges)
+        double v = 0.0;
+        if (e.kind <= MCX_EV_EXERCISE) {
+            double val = 0.0;
+#pragma unroll 1
+            for (int j = e.term_begin; j < e.term_end; ++j) {
+                val = fma(terms[j].w, f_atom<NREG>(terms[j].atom, reg), val);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (e.kind == MCX_EV_CASHFLOW) {
+                v = val * inv_num;
+            } else {
+                const double imm = fmax(e.sign * (val - e.strike), 0.0);
+                if (e.kind == MCX_EV_OPTION) {
+                    v = imm * inv_num;
+                } else {
+                    int s = 0;
+#pragma unroll
+                    for (int w = 0; w < NSTA; ++w) s = (e.sidx == w) ? est[w] : s;
+                    double cont = 0.0;
+                    if (e.coeff_off >= 0) cont = f_poly(a.coeffs + e.coeff_off + s * a.n_basis, a.n_basis, f_atom<NREG>(e.x, reg));
+                    const bool ex = (imm > cont) && (s > 0);
+                    v = ex ? imm * inv_num : 0.0;
+#pragma unroll
+                    for (int w = 0; w < NSTA; ++w) est[w] = (e.sidx == w && ex) ? s - 1 : est[w];
+                }
+            }
+#pragma unroll
+            for (int w = 0; w < NNS; ++w) cfs[w] += (NNS == 1 || e.ns == w) ? v : 0.0;
+        } else {
+            if (e.kind == MCX_EV_EXPO_POLY) {
+                int s = e.init_state;
+#pragma unroll
+                for (int w = 0; w < NSTA; ++w) s = (e.sidx == w) ? est[w] : s;
+                const double x = f_atom<NREG>(e.x, reg);
+                v = (e.coeff_off >= 0 ? f_poly(a.coeffs + e.coeff_off + s * a.n_basis, a.n_basis, x) : 0.0) * inv_num;
+            } else if (e.aux[2] > 0.0) {
+                const double spot = f_atom<NREG>(e.x, reg);
+                const double sig = e.aux[0], rate = e.aux[1], tau = e.aux[2], Kx = e.strike;
+                const double sq = sqrt(tau);
+                const double d1 = (log(spot / Kx) + (rate + 0.5 * sig * sig) * tau) / (sig * sq);
+                const double d2 = d1 - sig * sq;
+                const double df = exp(-rate * tau);
+                const double price = e.sign > 0.0 ? spot * f_norm_cdf(d1) - Kx * df * f_norm_cdf(d2)
+                                                  : Kx * df * f_norm_cdf(-d2) - spot * f_norm_cdf(-d1);
+                v = price * inv_num;
+            }
+#pragma unroll
+            for (int w = 0; w < NNS; ++w) e_ns[w] += (NNS == 1 || e.ns == w) ? v : 0.0;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int row = ldk(a.date_row + t);
+    if (a.expo && row >= 0 && live) {
+        for (int w = 0; w < a.n_ns; ++w) {
+            double ev = e_ns[0];
+#pragma unroll
+            for (int q = 1; q < NNS; ++q) ev = (w == q) ? e_ns[q] : ev;
+            a.expo[((int64_t)w * a.n_expo_rows + row) * a.ld_out + i] = ev;
+        }
+    }
+#pragma unroll 1
+    for (int q = 0; q < hd.n_mop; ++q) {
+        const FMetricOp& mo = mops[q];
+        double e = e_ns[0];
+#pragma unroll
+        for (int w = 1; w < NNS; ++w) e = (mo.ns == w) ? e_ns[w] : e;
+        const double u = dev_thr(e, mo.threshold);
+        if (mo.rec_profile >= 0) {
+            f_record(fmax(u, 0.0), live, mo.rec_profile, n_rec, first_tile, lds);
+            f_record(fmin(u, 0.0), live, mo.rec_profile + 1, n_rec, first_tile, lds);
+        }
+        if (mo.has_cva) {
+            const double sp = f_atom<NREG>(mo.surv, reg);
+            __builtin_amdgcn_sched_barrier(0);
+            const double cs = f_atom<NREG>(mo.cond, reg);
+            const double inc = fmax(u, 0.0) * (sp * (1.0 - cs));
+#pragma unroll
+            for (int w = 0; w < NNS; ++w) cva[w] += (NNS == 1 || mo.ns == w) ? inc : 0.0;
+        }
+    }
+}
+
+#ifndef MCX_KF_WAVES
+#define MCX_KF_WAVES 0     // 0: let the register allocator decide; n: cap VGPRs for >= n waves/SIMD (tuning knob)
+#endif
+#if MCX_KF_WAVES > 0
+#define MCX_KF_ATTR __attribute__((amdgpu_waves_per_eu(MCX_KF_WAVES, 8)))
+#else
+#define MCX_KF_ATTR
+#endif
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// NNS = compile-time bound on netting sets (1 or MCX_FUSED_MAX_NS), NST = bound on exercise products (0 -> none).
+// NPF = 1 KiB pieces of the NEXT date's program chunk each wave prefetches into VGPRs (one coalesced global_load_dwordx4
+// per piece, issued before the sub-steps that lead to that date, written to the wave's LDS slot just before use: the HBM/L2
+// latency hides under ~5 sub-steps of RNG + SDE work).  NPF = 0: chunks larger than 2 KiB are copied at use.
+template <int NSLOT, int NZ, bool INJECT, int SIG, int NNS, int NST, int NPF>
+__global__ __launch_bounds__(MCX_BLOCK) MCX_KF_ATTR void kf_fused(const FusedArgs a)
+{
+    constexpr int NREG = 2 * NSLOT;
+    constexpr int NSTA = NST > 0 ? NST : 1;
+    constexpr int NPFA = NPF > 0 ? NPF : 1;
     extern __shared__ double lds[];
     const K1Args& k = a.k1;
     const int n_rec = a.n_rec;
-    for (int q = threadIdx.x; q < n_rec + 4 * n_rec * 2; q += MCX_BLOCK) lds[q] = 0.0;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int rec_area = (9 * n_rec + 1) & ~1;                       // doubles; keeps the program slots 16-byte aligned
+    unsigned char* slot = (unsigned char*)(lds + rec_area) + (size_t)wv * a.chunk_cap;       // wave-private program slot
+    for (int q = threadIdx.x; q < 9 * n_rec; q += MCX_BLOCK) lds[q] = 0.0;
     __syncthreads();
     const int64_t tiles = (k.n + MCX_BLOCK - 1) / MCX_BLOCK;
     double n_block = 0.0;
-    const int D = k.n_state;
+
+    u32x4 pf[NPFA];
+    auto prefetch = [&](int t) {             // issue the loads of date t's chunk (NPF > 0)
+        if (NPF > 0 && t < a.n_dates) {
+            const int off = ldk(a.date_off + t), end = ldk(a.date_off + t + 1);
+#pragma unroll
+            for (int p = 0; p < NPFA; ++p) {
+                const int b = off + (p * 64 + lane) * 16;
+                pf[p] = b < end ? *(const u32x4*)(a.prog + b) : u32x4{0, 0, 0, 0};
+            }
+        }
+    };
+    auto stage = [&](int t) {                // make date t's chunk visible in the wave's LDS slot
+        if (NPF > 0) {
+#pragma unroll
+            for (int p = 0; p < NPFA; ++p) ((u32x4*)slot)[p * 64 + lane] = pf[p];
+        } else {
+            const int off = ldk(a.date_off + t), end = ldk(a.date_off + t + 1);
+            for (int b = lane * 16; b < end - off; b += 64 * 16) *(u32x4*)(slot + b) = *(const u32x4*)(a.prog + off + b);
+        }
+    };
+
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const bool first_tile = tile == (int64_t)blockIdx.x;
         const int64_t i_raw = tile * MCX_BLOCK + threadIdx.x;
@@ -117,150 +265,40 @@ __global__ __launch_bounds__(MCX_BLOCK) void kf_fused(const FusedArgs a)
         { const int64_t rest = k.n - tile * MCX_BLOCK; n_block += (double)(rest < MCX_BLOCK ? rest : MCX_BLOCK); }
 
         double reg[NREG];                                  // reg[2s], reg[2s+1] = state of slot s
+        sim_init_state<NSLOT, SIG>(k, reg);
+        double cfs[NNS], cva[NNS];
 #pragma unroll
-        for (int s = 0; s < NSLOT; ++s) {
-            reg[2 * s] = k.init_state[k.slots[s].state_off];
-            reg[2 * s + 1] = (k.slots[s].kind == MCX_MODEL_BS) ? 0.0 : k.init_state[k.slots[s].state_off + 1];
+        for (int q = 0; q < NNS; ++q) { cfs[q] = 0.0; cva[q] = 0.0; }
+        int est[NSTA];
+#pragma unroll
+        for (int q = 0; q < NSTA; ++q) est[q] = a.init_state[q];
+
+        int next_t = 0;                                    // timeline dates are visited in increasing order, each once
+        prefetch(0);
+        for (int t = 0; t < k.n_initial_store; ++t) {
+            stage(t);
+            prefetch(t + 1);
+            kf_on_date<NSLOT, SIG, NNS, NSTA>(a, t, i, live, first_tile, lds, slot, reg, cfs, cva, est);
+            next_t = t + 1;
         }
-        double cfs[MCX_FUSED_MAX_NS] = {0.0, 0.0, 0.0, 0.0};
-        double cva[MCX_FUSED_MAX_NS] = {0.0, 0.0, 0.0, 0.0};
-        int est[MCX_FUSED_MAX_STATEFUL];
-#pragma unroll
-        for (int q = 0; q < MCX_FUSED_MAX_STATEFUL; ++q) est[q] = a.init_state[q];
-
-        auto on_date = [&](int t) {
-            if (k.paths && live) {
-#pragma unroll
-                for (int s = 0; s < NSLOT; ++s) {
-                    const int c = k.slots[s].state_off;
-                    k.paths[((int64_t)t * D + c) * k.ld + i] = reg[2 * s];
-                    if (k.slots[s].kind != MCX_MODEL_BS) k.paths[((int64_t)t * D + c + 1) * k.ld + i] = reg[2 * s + 1];
-                }
-            }
-            double e_ns[MCX_FUSED_MAX_NS] = {0.0, 0.0, 0.0, 0.0};
-            for (int q = a.date_ev[t]; q < a.date_ev[t + 1]; ++q) {
-                const FEvent& e = a.events[q];
-                const double num = f_atom<NREG>(e.num, reg);
-                double v = 0.0;
-                if (e.kind <= MCX_EV_EXERCISE) {
-                    double val = 0.0;
-                    for (int j = e.term_begin; j < e.term_end; ++j) val = fma(a.terms[j].w, f_atom<NREG>(a.terms[j].atom, reg), val);
-                    if (e.kind == MCX_EV_CASHFLOW) {
-                        v = val / num;
-                    } else {
-                        const double imm = fmax(e.sign * (val - e.strike), 0.0);
-                        if (e.kind == MCX_EV_OPTION) {
-                            v = imm / num;
-                        } else {
-                            int s = 0;
-#pragma unroll
-                            for (int w = 0; w < MCX_FUSED_MAX_STATEFUL; ++w) s = (e.sidx == w) ? est[w] : s;
-                            double cont = 0.0;
-                            if (e.coeff_off >= 0) cont = f_poly(a.coeffs + e.coeff_off + s * a.n_basis, a.n_basis, f_atom<NREG>(e.x, reg));
-                            const bool ex = (imm > cont) && (s > 0);
-                            v = ex ? imm / num : 0.0;
-#pragma unroll
-                            for (int w = 0; w < MCX_FUSED_MAX_STATEFUL; ++w) est[w] = (e.sidx == w && ex) ? s - 1 : est[w];
-                        }
-                    }
-#pragma unroll
-                    for (int w = 0; w < MCX_FUSED_MAX_NS; ++w) cfs[w] += (e.ns == w) ? v : 0.0;
-                } else {
-                    if (e.kind == MCX_EV_EXPO_POLY) {
-                        int s = e.init_state;
-#pragma unroll
-                        for (int w = 0; w < MCX_FUSED_MAX_STATEFUL; ++w) s = (e.sidx == w) ? est[w] : s;
-                        const double x = f_atom<NREG>(e.x, reg);
-                        v = (e.coeff_off >= 0 ? f_poly(a.coeffs + e.coeff_off + s * a.n_basis, a.n_basis, x) : 0.0) / num;
-                    } else if (e.aux[2] > 0.0) {
-                        const double spot = f_atom<NREG>(e.x, reg);
-                        const double sig = e.aux[0], rate = e.aux[1], tau = e.aux[2], Kx = e.strike;
-                        const double sq = sqrt(tau);
-                        const double d1 = (log(spot / Kx) + (rate + 0.5 * sig * sig) * tau) / (sig * sq);
-                        const double d2 = d1 - sig * sq;
-                        const double df = exp(-rate * tau);
-                        const double price = e.sign > 0.0 ? spot * f_norm_cdf(d1) - Kx * df * f_norm_cdf(d2)
-                                                          : Kx * df * f_norm_cdf(-d2) - spot * f_norm_cdf(-d1);
-                        v = price / num;
-                    }
-#pragma unroll
-                    for (int w = 0; w < MCX_FUSED_MAX_NS; ++w) e_ns[w] += (e.ns == w) ? v : 0.0;
-                }
-            }
-            const int row = a.date_row[t];
-            if (a.expo && row >= 0 && live) {
-                for (int w = 0; w < a.n_ns; ++w) {
-                    double ev = e_ns[0];
-#pragma unroll
-                    for (int q = 1; q < MCX_FUSED_MAX_NS; ++q) ev = (w == q) ? e_ns[q] : ev;
-                    a.expo[((int64_t)w * a.n_expo_rows + row) * a.ld_out + i] = ev;
-                }
-            }
-            for (int q = a.date_mop[t]; q < a.date_mop[t + 1]; ++q) {
-                const FMetricOp& mo = a.mops[q];
-                double e = e_ns[0];
-#pragma unroll
-                for (int w = 1; w < MCX_FUSED_MAX_NS; ++w) e = (mo.ns == w) ? e_ns[w] : e;
-                const double u = dev_thr(e, mo.threshold);
-                if (mo.rec_profile >= 0) {
-                    f_record(fmax(u, 0.0), live, mo.rec_profile, n_rec, first_tile, lds);
-                    f_record(fmin(u, 0.0), live, mo.rec_profile + 1, n_rec, first_tile, lds);
-                }
-                if (mo.has_cva) {
-                    const double sp = f_atom<NREG>(mo.surv, reg), cs = f_atom<NREG>(mo.cond, reg);
-                    const double inc = fmax(u, 0.0) * (sp * (1.0 - cs));
-#pragma unroll
-                    for (int w = 0; w < MCX_FUSED_MAX_NS; ++w) cva[w] += (mo.ns == w) ? inc : 0.0;
-                }
-            }
-        };
-
-        for (int t = 0; t < k.n_initial_store; ++t) on_date(t);
         const uint64_t path = k.path_offset + (uint64_t)i;
+#pragma unroll 1
         for (int step = 0; step < k.n_steps; ++step) {
-            const mcx_step sp = k.steps[step];
-            double z[NZ], zc[NZ], u = 0.0;
-            if (INJECT) {
-#pragma unroll
-                for (int j = 0; j < NZ; ++j) z[j] = k.inject_z[((int64_t)step * NZ + j) * k.ld + i];
-                if (k.n_uniform) u = k.inject_u[(int64_t)step * k.ld + i];
-            } else {
-                double ua;
-#pragma unroll
-                for (int q = 0; q < (NZ + 1) / 2; ++q) {
-                    double z0, z1;
-                    draw_pair(k.seed, path, (uint32_t)step, (uint32_t)q, ua, z0, z1);
-                    z[2 * q] = z0;
-                    if (2 * q + 1 < NZ) z[2 * q + 1] = z1;
-                }
-                if (k.n_uniform) {
-                    double z0, z1;
-                    draw_pair(k.seed, path, (uint32_t)step, (uint32_t)((NZ + 1) / 2), u, z0, z1);
-                }
+            sim_substep<NSLOT, NZ, INJECT, SIG>(k, step, path, i, reg);
+            const int st = ldk(&k.steps[step].store_idx);
+            if (st >= 0) {
+                stage(st);
+                prefetch(st + 1);
+                kf_on_date<NSLOT, SIG, NNS, NSTA>(a, st, i, live, first_tile, lds, slot, reg, cfs, cva, est);
+                next_t = st + 1;
             }
-            const double* __restrict__ L = k.chol + (int64_t)sp.chol_idx * NZ * NZ;
-#pragma unroll
-            for (int r = 0; r < NZ; ++r) {
-                double acc = 0.0;
-#pragma unroll
-                for (int c = 0; c <= r; ++c) acc += L[r * NZ + c] * z[c];
-                zc[r] = acc;
-            }
-            const double* __restrict__ ax = k.aux + (int64_t)step * NSLOT * MCX_AUX;
-#pragma unroll
-            for (int s = 0; s < NSLOT; ++s) {
-                const double zc0 = (NSLOT == 1) ? zc[0] : zc[s < NZ ? s : 0];
-                const double zc1 = (NSLOT == 1 && NZ > 1) ? zc[NZ > 1 ? 1 : 0] : 0.0;
-                step_slot(k.slots[s], k.scheme, k.flags | k.slots[s].flags, sp.dt, sp.sqrt_dt, ax + s * MCX_AUX,
-                          reg[2 * s], reg[2 * s + 1], zc0, zc1, u);
-            }
-            if (sp.store_idx >= 0) on_date(sp.store_idx);
         }
+        (void)next_t;
         // per-path quantities
         for (int w = 0; w < a.n_ns; ++w) {
             double cv = cfs[0], cc = cva[0];
 #pragma unroll
-            for (int q = 1; q < MCX_FUSED_MAX_NS; ++q) { cv = (w == q) ? cfs[q] : cv; cc = (w == q) ? cva[q] : cc; }
+            for (int q = 1; q < NNS; ++q) { cv = (w == q) ? cfs[q] : cv; cc = (w == q) ? cva[q] : cc; }
             if (a.cfs && live) a.cfs[(int64_t)w * a.ld_out + i] = cv;
             if (a.rec_pv[w] >= 0) f_record(cv, live, a.rec_pv[w], n_rec, first_tile, lds);
             if (a.rec_cva[w] >= 0) f_record(cc * a.lgd[w], live, a.rec_cva[w], n_rec, first_tile, lds);
@@ -298,11 +336,22 @@ __global__ void kf_merge(const double* __restrict__ partials, int n_rec, int n_b
     out[r].n = N; out[r].shift = mean; out[r].s1 = 0.0; out[r].s2 = M2;
 }
 
-template <int NSLOT, int NZ>
-void launch_kf(const FusedArgs& a, int grid, size_t lds, bool inject, hipStream_t s)
+template <int NSLOT, int NZ, int SIG>
+void launch_kf(const FusedArgs& a, int grid, size_t lds, int npf, bool inject, hipStream_t s)
 {
-    if (inject) hipLaunchKernelGGL((kf_fused<NSLOT, NZ, true>), dim3(grid), dim3(MCX_BLOCK), lds, s, a);
-    else hipLaunchKernelGGL((kf_fused<NSLOT, NZ, false>), dim3(grid), dim3(MCX_BLOCK), lds, s, a);
+    const bool one_ns = a.n_ns == 1, no_state = a.n_stateful == 0;
+#define MCX_KF(INJ, NNS, NST, NPF) hipLaunchKernelGGL((kf_fused<NSLOT, NZ, INJ, SIG, NNS, NST, NPF>), dim3(grid), dim3(MCX_BLOCK), lds, s, a)
+#define MCX_KF_NPF(INJ, NNS, NST) do { if (npf == 1) MCX_KF(INJ, NNS, NST, 1); else if (npf == 2) MCX_KF(INJ, NNS, NST, 2); else MCX_KF(INJ, NNS, NST, 0); } while (0)
+    if (inject) {
+        if (one_ns && no_state) MCX_KF_NPF(true, 1, 0);
+        else MCX_KF(true, MCX_FUSED_MAX_NS, MCX_FUSED_MAX_STATEFUL, 0);
+    } else {
+        if (one_ns && no_state) MCX_KF_NPF(false, 1, 0);
+        else if (one_ns) MCX_KF_NPF(false, 1, MCX_FUSED_MAX_STATEFUL);
+        else MCX_KF(false, MCX_FUSED_MAX_NS, MCX_FUSED_MAX_STATEFUL, 0);
+    }
+#undef MCX_KF_NPF
+#undef MCX_KF
 }
 
 }  // namespace
@@ -311,12 +360,10 @@ struct mcx_fused {
     const mcx_sim* sim;
     const mcx_book* book;
     int n_rec, n_ns, n_dates, n_expo_rows, n_stateful, want_pv;
-    FTerm* d_terms;
-    FEvent* d_events;
-    FMetricOp* d_mops;
-    int32_t* d_date_ev;
-    int32_t* d_date_mop;
+    unsigned char* d_prog;
+    int32_t* d_date_off;
     int32_t* d_date_row;
+    int chunk_cap, npf;
     int32_t rec_pv[MCX_FUSED_MAX_NS], rec_cva[MCX_FUSED_MAX_NS];
     double lgd[MCX_FUSED_MAX_NS];
     int32_t init_state[MCX_FUSED_MAX_STATEFUL];
@@ -328,8 +375,7 @@ struct mcx_fused {
 extern "C" void mcx_fused_destroy(mcx_fused* f)
 {
     if (!f) return;
-    hipFree(f->d_terms); hipFree(f->d_events); hipFree(f->d_mops); hipFree(f->d_date_ev); hipFree(f->d_date_mop);
-    hipFree(f->d_date_row); hipFree(f->d_partials); hipFree(f->d_out);
+    hipFree(f->d_prog); hipFree(f->d_date_off); hipFree(f->d_date_row); hipFree(f->d_partials); hipFree(f->d_out);
     delete f;
 }
 
@@ -366,7 +412,7 @@ extern "C" int mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_boo
 
     // events bucketed by timeline date, product order preserved
     std::vector<std::vector<FEvent>> by_date(T);
-    std::vector<FTerm> terms;
+    std::vector<std::vector<FTerm>> terms_by_date(T);
     int n_stateful = 0;
     int32_t init_state[MCX_FUSED_MAX_STATEFUL] = {0, 0, 0, 0};
     if ((int)book->h_event_t_idx.size() != book->n_events) MCX_FAIL(h, -2, "mcx_fused_create: internal (event dates missing)");
@@ -390,6 +436,7 @@ extern "C" int mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_boo
             for (int w = 0; w < 4; ++w) fe.aux[w] = e.aux[w];
             fe.num = fatom(devatom_to_mcx(e.num), t);
             fe.x = fatom(devatom_to_mcx(e.x), t);
+            std::vector<FTerm>& terms = terms_by_date[t];
             fe.term_begin = (int)terms.size();
             for (int j = e.term_begin; j < e.term_end; ++j) {
                 if (hte[j].den >= 0) { ok = false; why = "a cashflow term carries its own numeraire (unequal swap tenors)"; break; }
@@ -397,6 +444,9 @@ extern "C" int mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_boo
                 terms.push_back(ft);
             }
             fe.term_end = (int)terms.size();
+            // numeraire identical to the previous event of this date: reuse 1/numeraire (flag bit1)
+            if (!by_date[t].empty() && memcmp(&by_date[t].back().num, &fe.num, sizeof(FAtom)) == 0) fe.flags |= 2;
+            else fe.flags &= ~2;
             by_date[t].push_back(fe);
         }
     }
@@ -440,19 +490,37 @@ extern "C" int mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_boo
     }
     if (!ok) { delete f; MCX_FAIL(h, MCX_E_NOT_FUSABLE, "not fusable: %s", why.c_str()); }
     if (n_rec < 1) { delete f; MCX_FAIL(h, MCX_E_NOT_FUSABLE, "not fusable: no reducible metric requested"); }
-    if ((size_t)(n_rec + 8 * n_rec) * sizeof(double) > 96 * 1024) { delete f; MCX_FAIL(h, MCX_E_NOT_FUSABLE, "not fusable: %d records exceed the LDS budget", n_rec); }
+    if ((size_t)9 * n_rec * sizeof(double) > 48 * 1024) { delete f; MCX_FAIL(h, MCX_E_NOT_FUSABLE, "not fusable: %d records exceed the LDS budget", n_rec); }
 
-    std::vector<FEvent> events;
-    std::vector<FMetricOp> mops;
-    std::vector<int32_t> date_ev(T + 1, 0), date_mop(T + 1, 0);
+    // per-date program chunks: header | events | terms | metric ops, 16-byte aligned
+    std::vector<unsigned char> prog;
+    std::vector<int32_t> date_off(T + 1, 0);
+    int max_chunk = 0;
     for (int t = 0; t < T; ++t) {
-        date_ev[t] = (int)events.size();
-        events.insert(events.end(), by_date[t].begin(), by_date[t].end());
-        date_mop[t] = (int)mops.size();
-        mops.insert(mops.end(), mop_by_date[t].begin(), mop_by_date[t].end());
+        date_off[t] = (int32_t)prog.size();
+        ChunkHeader hd;
+        hd.n_ev = (int)by_date[t].size(); hd.n_mop = (int)mop_by_date[t].size(); hd.n_terms = (int)terms_by_date[t].size();
+        const size_t bytes = sizeof(hd) + sizeof(FEvent) * by_date[t].size() + sizeof(FTerm) * terms_by_date[t].size() +
+                             sizeof(FMetricOp) * mop_by_date[t].size();
+        const size_t padded = (bytes + 15) & ~(size_t)15;
+        hd.bytes = (int32_t)padded;
+        const size_t base = prog.size();
+        prog.resize(base + padded, 0);
+        unsigned char* p = prog.data() + base;
+        memcpy(p, &hd, sizeof(hd)); p += sizeof(hd);
+        if (hd.n_ev) { memcpy(p, by_date[t].data(), sizeof(FEvent) * by_date[t].size()); p += sizeof(FEvent) * by_date[t].size(); }
+        if (hd.n_terms) { memcpy(p, terms_by_date[t].data(), sizeof(FTerm) * terms_by_date[t].size()); p += sizeof(FTerm) * terms_by_date[t].size(); }
+        if (hd.n_mop) memcpy(p, mop_by_date[t].data(), sizeof(FMetricOp) * mop_by_date[t].size());
+        max_chunk = std::max(max_chunk, (int)padded);
     }
-    date_ev[T] = (int)events.size();
-    date_mop[T] = (int)mops.size();
+    date_off[T] = (int32_t)prog.size();
+    // LDS budget: 4 wave slots + the record area must fit comfortably (several blocks per CU)
+    f->npf = max_chunk <= 1024 ? 1 : (max_chunk <= 2048 ? 2 : 0);
+    f->chunk_cap = f->npf > 0 ? f->npf * 1024 : ((max_chunk + 255) & ~255);
+    if ((size_t)4 * f->chunk_cap + sizeof(double) * 9 * (size_t)n_rec > 60 * 1024) {
+        delete f;
+        MCX_FAIL(h, MCX_E_NOT_FUSABLE, "not fusable: a date's event program (%d B) exceeds the per-wave LDS slot budget", max_chunk);
+    }
 
     f->sim = sim; f->book = book; f->n_rec = n_rec; f->n_ns = d->n_netting_sets; f->n_dates = T; f->n_expo_rows = d->n_expo_rows;
     f->n_stateful = n_stateful; f->want_pv = d->want_pv;
@@ -462,11 +530,9 @@ extern "C" int mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_boo
         if (e != hipSuccess) return e;
         return bytes ? hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
     };
-    MCX_HIP(h, up((void**)&f->d_terms, terms.data(), sizeof(FTerm) * terms.size()));
-    MCX_HIP(h, up((void**)&f->d_events, events.data(), sizeof(FEvent) * events.size()));
-    MCX_HIP(h, up((void**)&f->d_mops, mops.data(), sizeof(FMetricOp) * mops.size()));
-    MCX_HIP(h, up((void**)&f->d_date_ev, date_ev.data(), sizeof(int32_t) * date_ev.size()));
-    MCX_HIP(h, up((void**)&f->d_date_mop, date_mop.data(), sizeof(int32_t) * date_mop.size()));
+    prog.resize(prog.size() + 4096, 0);       // slack so the fixed-size prefetch of the last chunk stays in bounds
+    MCX_HIP(h, up((void**)&f->d_prog, prog.data(), prog.size()));
+    MCX_HIP(h, up((void**)&f->d_date_off, date_off.data(), sizeof(int32_t) * date_off.size()));
     MCX_HIP(h, up((void**)&f->d_date_row, date_row.data(), sizeof(int32_t) * date_row.size()));
     f->partial_bytes = sizeof(double) * 4 * (size_t)n_rec * 2048;
     MCX_HIP(h, hipMalloc(&f->d_partials, f->partial_bytes));
@@ -489,7 +555,7 @@ extern "C" int mcx_fused_run(mcx_handle* h, const mcx_fused* f, uint64_t seed, u
     FusedArgs a;
     memset(&a, 0, sizeof(a));
     mcx_fill_k1_args(f->sim, seed, path_offset, n_paths, ld > 0 ? ld : n_paths, d_paths, d_inject_z, d_inject_u, &a.k1);
-    a.terms = f->d_terms; a.events = f->d_events; a.mops = f->d_mops; a.date_ev = f->d_date_ev; a.date_mop = f->d_date_mop;
+    a.prog = f->d_prog; a.date_off = f->d_date_off; a.chunk_cap = f->chunk_cap;
     a.date_row = f->d_date_row; a.coeffs = f->book->d_coeffs; a.cfs = d_cfs; a.expo = d_expo; a.partials = f->d_partials;
     a.ld_out = ld_out; a.n_dates = f->n_dates; a.n_basis = f->book->n_basis; a.n_ns = f->n_ns; a.n_rec = f->n_rec;
     a.n_expo_rows = f->n_expo_rows; a.n_stateful = f->n_stateful;
@@ -499,16 +565,27 @@ extern "C" int mcx_fused_run(mcx_handle* h, const mcx_fused* f, uint64_t seed, u
     int grid = (int)std::min<int64_t>(tiles, 2048);
     // keep the tiles-per-block count integral when possible (equal work per block)
     if (tiles > 2048) { int per = (int)((tiles + 2047) / 2048); grid = (int)((tiles + per - 1) / per); }
-    const size_t lds = sizeof(double) * (size_t)(f->n_rec + 8 * f->n_rec);
+    const size_t lds = sizeof(double) * (size_t)((9 * f->n_rec + 1) & ~1) + (size_t)4 * f->chunk_cap;
     hipStream_t s = (hipStream_t)stream;
     const bool inj = d_inject_z != nullptr;
-    switch (sd.n_slots * 16 + sd.n_z) {
-    case 1 * 16 + 1: launch_kf<1, 1>(a, grid, lds, inj, s); break;
-    case 1 * 16 + 2: launch_kf<1, 2>(a, grid, lds, inj, s); break;
-    case 2 * 16 + 2: launch_kf<2, 2>(a, grid, lds, inj, s); break;
-    case 3 * 16 + 3: launch_kf<3, 3>(a, grid, lds, inj, s); break;
-    case 4 * 16 + 4: launch_kf<4, 4>(a, grid, lds, inj, s); break;
-    default: MCX_FAIL(h, MCX_E_NOT_FUSABLE, "not fusable: (slots=%d, z=%d) has no fused instantiation", sd.n_slots, sd.n_z);
+    switch (mcx_sim_signature(sd)) {
+    case SIG_VAS_CIR_E: launch_kf<2, 2, SIG_VAS_CIR_E>(a, grid, lds, f->npf, inj, s); break;
+    case SIG_BS_A: launch_kf<1, 1, SIG_BS_A>(a, grid, lds, f->npf, inj, s); break;
+    case SIG_BS_E: launch_kf<1, 1, SIG_BS_E>(a, grid, lds, f->npf, inj, s); break;
+    case SIG_HESTON_QE: launch_kf<1, 2, SIG_HESTON_QE>(a, grid, lds, f->npf, inj, s); break;
+    case SIG_HESTON_E: launch_kf<1, 2, SIG_HESTON_E>(a, grid, lds, f->npf, inj, s); break;
+    case SIG_VAS_E: launch_kf<1, 1, SIG_VAS_E>(a, grid, lds, f->npf, inj, s); break;
+    case SIG_VAS_A: launch_kf<1, 1, SIG_VAS_A>(a, grid, lds, f->npf, inj, s); break;
+    case SIG_BS_VAS_CIRDET_E: launch_kf<3, 3, SIG_BS_VAS_CIRDET_E>(a, grid, lds, f->npf, inj, s); break;
+    default:
+        switch (sd.n_slots * 16 + sd.n_z) {
+        case 1 * 16 + 1: launch_kf<1, 1, SIG_GENERIC>(a, grid, lds, f->npf, inj, s); break;
+        case 1 * 16 + 2: launch_kf<1, 2, SIG_GENERIC>(a, grid, lds, f->npf, inj, s); break;
+        case 2 * 16 + 2: launch_kf<2, 2, SIG_GENERIC>(a, grid, lds, f->npf, inj, s); break;
+        case 3 * 16 + 3: launch_kf<3, 3, SIG_GENERIC>(a, grid, lds, f->npf, inj, s); break;
+        case 4 * 16 + 4: launch_kf<4, 4, SIG_GENERIC>(a, grid, lds, f->npf, inj, s); break;
+        default: MCX_FAIL(h, MCX_E_NOT_FUSABLE, "not fusable: (slots=%d, z=%d) has no fused instantiation", sd.n_slots, sd.n_z);
+        }
     }
     MCX_HIP(h, hipGetLastError());
     hipLaunchKernelGGL(kf_merge, dim3((f->n_rec + 63) / 64), dim3(64), 0, s, f->d_partials, f->n_rec, grid, f->d_out);

@@ -79,14 +79,18 @@ __device__ __forceinline__ double degree_of_truth(double x, bool fuzzy, double e
 }
 
 // one sub-step of one sub-model (reference formulas, see oracle/mcx_oracle.c for the line-by-line citations)
-__device__ __forceinline__ void step_slot(const mcx_slot& sl, int scheme, int flags, double dt, double sq,
+// KIND / SCHEME >= 0 are compile-time constants (specialised kernels: the switch folds away and only the parameters the
+// model really uses stay live in SGPRs); -1 = wave-uniform run-time dispatch (generic kernels).
+template <int KIND, int SCHEME>
+__device__ __forceinline__ void step_slot(const mcx_slot& sl, int scheme_rt, int flags, double dt, double sq,
                                           const double* __restrict__ aux, double& s0, double& s1, double zc0, double zc1, double u)
 {
     const double* p = sl.p;
-    switch (sl.kind) {
+    const int scheme = SCHEME >= 0 ? SCHEME : scheme_rt;
+    switch (KIND >= 0 ? KIND : sl.kind) {
     case MCX_MODEL_BS:
         if (scheme == MCX_SCHEME_ANALYTICAL) {
-            s0 = s0 * exp(aux[0] + (zc0 - aux[1]));                       // black_scholes.py:61-67
+            s0 = s0 * exp(ldk(aux + 0) + (zc0 - ldk(aux + 1)));                       // black_scholes.py:61-67
         } else {
             s0 = s0 + (p[2] * s0 * dt + p[1] * s0 * sq * zc0);           // black_scholes.py:79-85
         }
@@ -94,28 +98,28 @@ __device__ __forceinline__ void step_slot(const mcx_slot& sl, int scheme, int fl
     case MCX_MODEL_VASICEK: {
         const double r = s0;
         s1 = s1 + r * dt;                                                 // left-endpoint integral, vasicek.py:80/107
-        if (scheme == MCX_SCHEME_ANALYTICAL) s0 = (p[2] + (r - p[2]) * aux[0]) + zc0;
+        if (scheme == MCX_SCHEME_ANALYTICAL) s0 = (p[2] + (r - p[2]) * ldk(aux + 0)) + zc0;
         else s0 = r + p[3] * (p[2] - r) * dt + p[1] * sq * zc0;
         break;
     }
     case MCX_MODEL_HW: {
         const double r = s0;
         s1 = s1 + r * dt;
-        if (scheme == MCX_SCHEME_ANALYTICAL) s0 = r * aux[0] + aux[1] + zc0;
-        else s0 = r + (aux[0] - p[3] * r) * dt + p[1] * sq * zc0;
+        if (scheme == MCX_SCHEME_ANALYTICAL) s0 = r * ldk(aux + 0) + ldk(aux + 1) + zc0;
+        else s0 = r + (ldk(aux + 0) - p[3] * r) * dt + p[1] * sq * zc0;
         break;
     }
     case MCX_MODEL_CIRPP: {                                               // cirpp.py:188-198
         const double y = s0;
         const double sy = sqrt(fmax(y, 0.0));
         const double yn = y + p[0] * (p[1] - y) * dt + p[2] * sy * sq * zc0;
-        s1 = s1 + (y + aux[0]) * dt;
+        s1 = s1 + (y + ldk(aux + 0)) * dt;
         s0 = fmax(yn, 1e-12);
         break;
     }
     case MCX_MODEL_CIRPP_DET:                                             // cirpp.py:155-172
-        s1 = s1 + aux[0] * dt;
-        s0 = aux[1];
+        s1 = s1 + ldk(aux + 0) * dt;
+        s0 = ldk(aux + 1);
         break;
     case MCX_MODEL_HESTON: {
         const double logS = s0, v = s1;
@@ -127,8 +131,8 @@ __device__ __forceinline__ void step_slot(const mcx_slot& sl, int scheme, int fl
         } else {                                                          // heston.py:161-253 (Andersen QE)
             const double eps = 1e-12;
             const bool fuzzy = (flags & MCX_FLAG_SMOOTHING) != 0;
-            const double m = theta + (v - theta) * aux[0];
-            const double s2 = v * aux[6] + aux[7];
+            const double m = theta + (v - theta) * ldk(aux + 0);
+            const double s2 = v * ldk(aux + 6) + ldk(aux + 7);
             const double psi = s2 / (m * m + eps);
             const double invpsi = 1.0 / (psi + eps);
             const double t = fmax(2.0 * invpsi - 1.0, 0.0);
@@ -144,9 +148,9 @@ __device__ __forceinline__ void step_slot(const mcx_slot& sl, int scheme, int fl
             const double v2 = degree_of_truth(u - pp, fuzzy, 0.3) * v_tail;
             const double w = degree_of_truth(psi - 1.5, fuzzy, 0.5);
             const double vn = (1.0 - w) * v1 + w * v2;
-            const double var_int = fmax(aux[4] * v + aux[5] * vn, 0.0);
+            const double var_int = fmax(ldk(aux + 4) * v + ldk(aux + 5) * vn, 0.0);
             const double vol = sqrt(fmax(var_int, eps));
-            s0 = logS + rate * dt + aux[1] + aux[2] * v + aux[3] * vn + vol * zc0;
+            s0 = logS + rate * dt + ldk(aux + 1) + ldk(aux + 2) * v + ldk(aux + 3) * vn + vol * zc0;
             s1 = vn;
         }
         break;
@@ -155,3 +159,114 @@ __device__ __forceinline__ void step_slot(const mcx_slot& sl, int scheme, int fl
     }
 }
 
+
+// ---- model signatures: compile-time (kinds, scheme) of the hot configurations ---------------------------------------
+enum { SIG_GENERIC = 0, SIG_VAS_CIR_E = 1, SIG_BS_A = 2, SIG_BS_E = 3, SIG_HESTON_QE = 4, SIG_HESTON_E = 5,
+       SIG_VAS_E = 6, SIG_VAS_A = 7, SIG_BS_VAS_CIRDET_E = 8 };
+
+__host__ __device__ constexpr int sig_kind(int sig, int slot)
+{
+    return sig == SIG_VAS_CIR_E ? (slot == 0 ? MCX_MODEL_VASICEK : MCX_MODEL_CIRPP)
+         : (sig == SIG_BS_A || sig == SIG_BS_E) ? MCX_MODEL_BS
+         : (sig == SIG_HESTON_QE || sig == SIG_HESTON_E) ? MCX_MODEL_HESTON
+         : (sig == SIG_VAS_E || sig == SIG_VAS_A) ? MCX_MODEL_VASICEK
+         : sig == SIG_BS_VAS_CIRDET_E ? (slot == 0 ? MCX_MODEL_BS : slot == 1 ? MCX_MODEL_VASICEK : MCX_MODEL_CIRPP_DET)
+         : -1;
+}
+__host__ __device__ constexpr int sig_scheme(int sig)
+{
+    return (sig == SIG_VAS_CIR_E || sig == SIG_BS_E || sig == SIG_HESTON_E || sig == SIG_VAS_E || sig == SIG_BS_VAS_CIRDET_E) ? MCX_SCHEME_EULER
+         : (sig == SIG_BS_A || sig == SIG_VAS_A) ? MCX_SCHEME_ANALYTICAL
+         : sig == SIG_HESTON_QE ? MCX_SCHEME_QE : -1;
+}
+__host__ __device__ constexpr bool sig_is_bs(int sig, int slot) { return sig_kind(sig, slot) == MCX_MODEL_BS; }
+
+// signature of a simulation descriptor (host)
+static inline int mcx_sim_signature(const mcx_sim_desc& d)
+{
+    auto k = [&](int s) { return d.slots[s].kind; };
+    if (d.n_slots == 2 && k(0) == MCX_MODEL_VASICEK && k(1) == MCX_MODEL_CIRPP && d.scheme == MCX_SCHEME_EULER) return SIG_VAS_CIR_E;
+    if (d.n_slots == 3 && k(0) == MCX_MODEL_BS && k(1) == MCX_MODEL_VASICEK && k(2) == MCX_MODEL_CIRPP_DET && d.scheme == MCX_SCHEME_EULER)
+        return SIG_BS_VAS_CIRDET_E;
+    if (d.n_slots == 1) {
+        if (k(0) == MCX_MODEL_BS) return d.scheme == MCX_SCHEME_ANALYTICAL ? SIG_BS_A : d.scheme == MCX_SCHEME_EULER ? SIG_BS_E : SIG_GENERIC;
+        if (k(0) == MCX_MODEL_HESTON) return d.scheme == MCX_SCHEME_QE ? SIG_HESTON_QE : d.scheme == MCX_SCHEME_EULER ? SIG_HESTON_E : SIG_GENERIC;
+        if (k(0) == MCX_MODEL_VASICEK) return d.scheme == MCX_SCHEME_EULER ? SIG_VAS_E : d.scheme == MCX_SCHEME_ANALYTICAL ? SIG_VAS_A : SIG_GENERIC;
+    }
+    return SIG_GENERIC;
+}
+
+// compile-time recursion over the slots (the slot index must be a constant expression for the signature lookup)
+template <int NSLOT, int NZ, int SIG, int S>
+__device__ __forceinline__ void step_slots(const K1Args& k, const mcx_step& sp, const double* __restrict__ ax,
+                                           double (&reg)[2 * NSLOT], const double (&zc)[NZ], double u)
+{
+    if constexpr (S < NSLOT) {
+        // ModelConfig only hosts sub-models with simulation_dim == 1 (model_config.py:106-107); Heston runs alone
+        const double zc0 = (NSLOT == 1) ? zc[0] : zc[S < NZ ? S : 0];
+        const double zc1 = (NSLOT == 1 && NZ > 1) ? zc[NZ > 1 ? 1 : 0] : 0.0;
+        step_slot<sig_kind(SIG, S), sig_scheme(SIG)>(k.slots[S], k.scheme, k.flags | k.slots[S].flags, sp.dt, sp.sqrt_dt,
+                                                      ax + S * MCX_AUX, reg[2 * S], reg[2 * S + 1], zc0, zc1, u);
+        step_slots<NSLOT, NZ, SIG, S + 1>(k, sp, ax, reg, zc, u);
+    }
+}
+
+// one sub-step of the whole model for a lane: draws, Cholesky, per-slot maps.  reg[2s], reg[2s+1] = state of slot s.
+template <int NSLOT, int NZ, bool INJECT, int SIG>
+__device__ __forceinline__ void sim_substep(const K1Args& k, int step, uint64_t path, int64_t i, double (&reg)[2 * NSLOT])
+{
+    const mcx_step sp = ldk_struct(&k.steps[step]);    // wave-uniform -> scalar loads
+    double z[NZ], zc[NZ], u = 0.0;
+    if (INJECT) {
+#pragma unroll
+        for (int j = 0; j < NZ; ++j) z[j] = k.inject_z[((int64_t)step * NZ + j) * k.ld + i];
+        if (k.n_uniform) u = k.inject_u[(int64_t)step * k.ld + i];
+    } else {
+        double ua;
+#pragma unroll
+        for (int q = 0; q < (NZ + 1) / 2; ++q) {
+            double z0, z1;
+            draw_pair(k.seed, path, (uint32_t)step, (uint32_t)q, ua, z0, z1);
+            z[2 * q] = z0;
+            if (2 * q + 1 < NZ) z[2 * q + 1] = z1;
+        }
+        if (sig_scheme(SIG) == MCX_SCHEME_QE || (sig_scheme(SIG) < 0 && k.n_uniform)) {
+            double z0, z1;
+            draw_pair(k.seed, path, (uint32_t)step, (uint32_t)((NZ + 1) / 2), u, z0, z1);
+        }
+    }
+    const double* __restrict__ L = k.chol + (int64_t)sp.chol_idx * NZ * NZ;     // model.py:48  z @ chol.T
+#pragma unroll
+    for (int r = 0; r < NZ; ++r) {
+        double acc = 0.0;
+#pragma unroll
+        for (int c = 0; c <= r; ++c) acc += ldk(L + r * NZ + c) * z[c];
+        zc[r] = acc;
+    }
+    const double* __restrict__ ax = k.aux + (int64_t)step * NSLOT * MCX_AUX;
+    step_slots<NSLOT, NZ, SIG, 0>(k, sp, ax, reg, zc, u);
+}
+
+template <int NSLOT, int SIG>
+__device__ __forceinline__ void sim_init_state(const K1Args& k, double (&reg)[2 * NSLOT])
+{
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+        const bool bs = sig_kind(SIG, s) >= 0 ? sig_is_bs(SIG, s) : (k.slots[s].kind == MCX_MODEL_BS);
+        reg[2 * s] = k.init_state[k.slots[s].state_off];
+        reg[2 * s + 1] = bs ? 0.0 : k.init_state[k.slots[s].state_off + 1];
+    }
+}
+
+template <int NSLOT, int SIG>
+__device__ __forceinline__ void sim_store_state(const K1Args& k, int t, int64_t i, const double (&reg)[2 * NSLOT])
+{
+    const int D = k.n_state;
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+        const bool bs = sig_kind(SIG, s) >= 0 ? sig_is_bs(SIG, s) : (k.slots[s].kind == MCX_MODEL_BS);
+        const int c = k.slots[s].state_off;
+        k.paths[((int64_t)t * D + c) * k.ld + i] = reg[2 * s];
+        if (!bs) k.paths[((int64_t)t * D + c + 1) * k.ld + i] = reg[2 * s + 1];
+    }
+}

@@ -97,6 +97,28 @@ struct mcx_sim {
 };
 
 // ---- device helpers -------------------------------------------------------------------------------------------------
+// Read-only, wave-uniform table loads.  Kernel tables (sub-step table, Cholesky factors, event program, coefficients) are
+// indexed by wave-uniform counters; reading them through the CONSTANT address space lets the backend issue scalar loads
+// (s_load_dwordx*, scalar cache -> SGPRs) instead of 64 identical vector loads that occupy VGPRs.  (`__restrict__` on
+// struct members does not give the alias information the backend needs to do this on its own.)
+#define MCX_KONST __attribute__((address_space(4)))
+template <class T>
+__device__ __forceinline__ T ldk(const T* p)
+{
+    return *(const MCX_KONST T*)(uintptr_t)p;
+}
+template <class T>
+__device__ __forceinline__ T ldk_struct(const T* p)
+{
+    static_assert(sizeof(T) % 4 == 0, "dword-sized records only");
+    T out;
+    uint32_t* o = (uint32_t*)&out;
+    const MCX_KONST uint32_t* s = (const MCX_KONST uint32_t*)(uintptr_t)p;
+#pragma unroll
+    for (unsigned q = 0; q < sizeof(T) / 4; ++q) o[q] = s[q];
+    return out;
+}
+
 __device__ __forceinline__ double dev_atom(const DevAtom& a, const double* __restrict__ paths, int64_t D, int64_t ld, int64_t i)
 {
     double x = 0.0;
@@ -166,11 +188,11 @@ __device__ __forceinline__ double dev_thr(double x, double h)
 
 __device__ __forceinline__ double dev_unsec(const DevUnsec& u, const double* __restrict__ expo, int64_t ld, int m, int64_t i)
 {
-    double e = expo[(int64_t)u.row[m] * ld + i];
+    double e = expo[(int64_t)ldk(u.row + m) * ld + i];
     if (!u.collateralized) return dev_thr(e, u.threshold);
     double coll = 0.0;
     if (u.delayed) {
-        int dm = u.delayed[m];
+        int dm = ldk(u.delayed + m);
         if (dm >= 0) coll = dev_thr(expo[(int64_t)dm * ld + i], u.threshold);
     }
     return e - coll;
