@@ -1,0 +1,73 @@
+"""Host API parity with the reference's surface: constructors, error behaviour, names, results access
+(reference tests: test_simulation_results_named_access.py, controller.py:40-48, 89-97)."""
+import numpy as np
+import pytest
+
+import cases
+from mcx.common.enums import SimulationScheme
+from mcx.controller.controller import SimulationController
+from mcx.controller.simulation_results import SimulationResults
+from mcx.metrics.cva_metric import CVAMetric
+from mcx.metrics.pfe_metric import PFEMetric
+from mcx.metrics.pv_metric import PVMetric
+from mcx.metrics.risk_metrics import RiskMetrics
+from mcx.models.black_scholes import BlackScholesModel
+from mcx.products.equity import Equity
+from mcx.products.european_option import EuropeanOption
+from mcx.products.netting_set import NettingSet
+from mcx.products.product import OptionType
+
+
+def test_constructor_errors(oracle):
+    model = BlackScholesModel(0, 100.0, 0.05, 0.2)
+    prod = EuropeanOption(Equity(), 1.0, 100.0, OptionType.CALL)
+    ns = NettingSet(name="a", products=[prod])
+    rm = RiskMetrics([PVMetric()])
+    with pytest.raises(ValueError):
+        SimulationController([], model, rm, 10, 0, 1, SimulationScheme.ANALYTICAL, backend=oracle)
+    with pytest.raises(ValueError):
+        SimulationController([ns, NettingSet(name="b", products=[prod])], model, rm, 10, 0, 1, SimulationScheme.ANALYTICAL, backend=oracle)
+    with pytest.raises(Exception, match="ModelConfig"):
+        SimulationController([ns], model, RiskMetrics([CVAMetric("cp", 0.4)], exposure_timeline=[0.0, 1.0]), 10, 10, 1,
+                             SimulationScheme.ANALYTICAL, backend=oracle)
+    with pytest.raises(ValueError):
+        NettingSet(name="x", products=[])
+    with pytest.raises(ValueError):
+        NettingSet(name="x", products=[prod], threshold=-1.0)
+
+
+def test_metric_and_param_names():
+    assert PFEMetric(0.95).get_name() == "pfe[0.95]"
+    assert CVAMetric("cp", 0.4).get_name() == "cva[cp]"
+    ns, model, rm = cases.mixed_cva()
+    assert model.get_model_param_names()[:4] == ["equity.spot", "equity.volatility", "equity.rate", "rates.rate"]
+    assert SimulationController._make_unique_names(["a", "b", "a"]) == ["a", "b", "a#2"]
+    assert PFEMetric(0.95).q_index(1024) == 972 and PFEMetric(0.95).q_index(1000000) == 949999
+
+
+def test_simulation_results_named_and_legacy_access():
+    res = SimulationResults([[[(1.0, 0.1), (2.0, 0.2)], [(3.0, 0.3)]]], [[[(0.5, 0.6), (0.7, 0.8)], [(0.9, 1.0)]]], [],
+                            netting_set_names=["NS"], metric_names=["epe", "pv"], model_param_names=["spot", "vol"])
+    assert np.array_equal(res.get_results("ns", "EPE"), [1.0, 2.0])
+    assert res.get_results(0, 1, evaluation_idx=0) == 3.0
+    assert res.get_mc_error(product="NS", metric_idx=0, evaluation_index=1) == 0.2
+    assert res.get_derivatives("NS", "pv", evaluation_idx=0) == {"spot": 0.9, "vol": 1.0}
+    assert res.get_derivatives("NS", "epe", param="vol", evaluation_idx=1) == 0.8
+    with pytest.raises(KeyError):
+        res.get_results("nope", "pv")
+    with pytest.raises(TypeError):
+        res.get_results("NS", "pv", bogus=1)
+    with pytest.raises(ValueError):
+        res.get_results("NS", "pv", prod_idx=0, product=1)
+
+
+def test_analytic_pv_metric_skips_monte_carlo(oracle):
+    from mcx.metrics.metric import Metric
+    model = BlackScholesModel(0, 120.0, 0.05, 0.2)
+    prod = EuropeanOption(Equity(), 2.0, 100.0, OptionType.CALL)
+    ns = NettingSet(name="a", products=[prod])
+    rm = RiskMetrics([PVMetric(evaluation_type=Metric.EvaluationType.ANALYTICAL)])
+    sc = SimulationController([ns], model, rm, 1, 0, 1, SimulationScheme.ANALYTICAL, backend=oracle)
+    res = sc.run_simulation()
+    assert res.get_results("a", "pv", 0) == pytest.approx(31.96482, abs=1e-4)
+    assert res.get_mc_error("a", "pv", 0) == 0.0
