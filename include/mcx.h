@@ -270,6 +270,24 @@ int  mcx_fused_run(mcx_handle* h, const mcx_fused* f, uint64_t seed, uint64_t pa
                    double* d_paths, int64_t ld, double* d_cfs, double* d_expo, int64_t ld_out,
                    const double* d_inject_z, const double* d_inject_u, mcx_acc* h_out, void* stream);
 
+/* Tangent (forward-mode) pass — replaces `torch.autograd.grad(value, model.get_model_params())` (controller.py:609-627) for
+ * PV metrics of European options under a single Black-Scholes or Heston model (BASELINE configs 2 and 4): the path kernel
+ * carries d state / d theta_j for every model parameter in dual numbers (same smoothing / subgradient conventions as
+ * torch: clamp passes the gradient on [min, max], torch.maximum splits ties).  Outputs per path:
+ *   d_cfs  [n_netting_sets][ld_out]                 normalised cashflows (primal, with smoothing on)
+ *   d_dcfs [n_netting_sets][n_params][ld_out]       d cfs / d theta_j     (parameter order = model.get_model_params()) */
+typedef struct {
+    int32_t t_idx;            /* timeline index of the exercise date                     */
+    int32_t netting_set;
+    double  strike, sign;     /* +1 call / -1 put                                        */
+    double  numeraire;        /* exp(rate * (T - t0))                                    */
+    double  dnum_drate;       /* d numeraire / d rate = (T - t0) * numeraire             */
+} mcx_tangent_option;
+int  mcx_tangent_european(mcx_handle* h, const mcx_sim* sim, const mcx_tangent_option* h_opts, int32_t n_opts,
+                          int32_t n_netting_sets, uint64_t seed, uint64_t path_offset, int64_t n_paths, int64_t ld,
+                          double* d_cfs, double* d_dcfs, int64_t ld_out, const double* d_inject_z, const double* d_inject_u,
+                          void* stream);
+
 /* K3 — Longstaff-Schwartz normal equations (controller/controller.py:316-374).
  * mcx_lsm_stats: h_out[2*i+0] = min x_i, h_out[2*i+1] = max x_i over local paths for each explanatory atom (basis centring /
  *                scaling z = (x-shift)*scale, and detection of the exactly rank-1 regression at the calibration date).

@@ -22,7 +22,7 @@ _EXPORTS = [
     "mcx_sim_create", "mcx_sim_destroy", "mcx_generate_paths",
     "mcx_book_create", "mcx_book_destroy", "mcx_book_set_coeffs", "mcx_eval_book", "mcx_resolve_atoms",
     "mcx_lsm_stats", "mcx_lsm_step",
-    "mcx_fused_create", "mcx_fused_destroy", "mcx_fused_num_records", "mcx_fused_run",
+    "mcx_tangent_european", "mcx_fused_create", "mcx_fused_destroy", "mcx_fused_num_records", "mcx_fused_run",
     "mcx_reduce_vector", "mcx_reduce_profiles", "mcx_reduce_cva", "mcx_unsecured", "mcx_select_hist",
 ]
 
@@ -182,6 +182,18 @@ class HipBackend:
             self.h, fused.ptr, C.c_uint64(seed), C.c_uint64(path_offset), C.c_int64(n_paths), dp(paths), C.c_int64(n_paths),
             dp(cfs), dp(expo), C.c_int64(n_paths), dp(inject_z), dp(inject_u), _abi.ptr(out), self._stream()), "mcx_fused_run")
         return out
+
+    # ---- tangents ------------------------------------------------------------------------------------------------
+    def tangent_european(self, sim, opts, n_ns: int, n_params: int, seed: int, path_offset: int, n_paths: int,
+                         inject_z=None, inject_u=None):
+        cfs = self.empty(n_ns, n_paths)
+        dcfs = self.empty(n_ns, n_params, n_paths)
+        dp = lambda t: _vp(t.data_ptr() if t is not None else 0)
+        self._check(self.lib.mcx_tangent_european(
+            self.h, sim.ptr, opts, C.c_int32(len(opts)), C.c_int32(n_ns), C.c_uint64(seed), C.c_uint64(path_offset),
+            C.c_int64(n_paths), C.c_int64(n_paths), dp(cfs), dp(dcfs), C.c_int64(n_paths), dp(inject_z), dp(inject_u),
+            self._stream()), "mcx_tangent_european")
+        return cfs, dcfs
 
     # ---- K3 ------------------------------------------------------------------------------------------------------
     def lsm_stats(self, book, atom_ids, paths: torch.Tensor) -> np.ndarray:

@@ -156,6 +156,15 @@ class OracleBackend:
                                  C.c_int32(shift), C.c_int32(bits), _p(hist))
         return hist
 
+    def tangent_european(self, sim, opts, n_ns, n_params, seed, path_offset, n_paths, inject_z=None, inject_u=None):
+        cfs = torch.empty(n_ns, n_paths, dtype=torch.float64)
+        dcfs = torch.empty(n_ns, n_params, n_paths, dtype=torch.float64)
+        rc = self.lib.orc_tangent_european(C.byref(sim.plan.desc), opts, C.c_int32(len(opts)), C.c_int32(n_ns),
+                                           C.c_uint64(seed), C.c_uint64(path_offset), C.c_int64(n_paths), C.c_int64(n_paths),
+                                           _p(cfs), _p(dcfs), C.c_int64(n_paths), _p(inject_z), _p(inject_u))
+        assert rc == 0
+        return cfs, dcfs
+
     # the "fused pass" of the oracle is simply the composition of its primitives with the same record layout
     def fused_create(self, sim, book, plan):
         f = _Obj(plan)

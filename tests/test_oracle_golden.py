@@ -59,3 +59,21 @@ def test_case_against_reference(name, oracle):
             assert np.allclose(ours[:, 1], ref[:, 1], rtol=1e-6, atol=1e-12), (name, metric.get_name(), ours[:, 1], ref[:, 1])
     assert list(res.metric_names) == list(g["metric_names"])
     assert list(res.netting_set_names) == list(g["netting_set_names"])
+
+
+AAD = [n for n, c in cases.CASES.items() if c[5]]
+
+
+@pytest.mark.parametrize("name", AAD)
+def test_tangents_against_reference_autograd(name, oracle):
+    """differentiate=True: PV (smoothed primal) and d PV / d theta for every model parameter vs torch.autograd"""
+    sc, g = cases.make_controller(name, oracle)
+    res = sc.run_simulation()
+    ref = g["result_0_0"]
+    ours = np.array(res.results[0][0], dtype=np.float64)
+    assert np.allclose(ours, ref, rtol=1e-10), (ours, ref)
+    grads = np.array(res.derivatives[0][0][0], dtype=np.float64)
+    assert np.allclose(grads, g["grad_0_0"][0], rtol=1e-7, atol=1e-9), (grads, g["grad_0_0"][0])
+    assert list(res.model_param_names) == list(g["param_names"])
+    d = res.get_derivatives(0, "pv", evaluation_idx=0)
+    assert set(d) == set(g["param_names"])
