@@ -20,26 +20,44 @@
 namespace {
 
 
+#ifndef MCX_K1_PPL
+#define MCX_K1_PPL 1      // paths per lane: 2 interleaves two independent RNG/SDE dependency chains per lane (ILP)
+#endif
 template <int NSLOT, int NZ, bool INJECT, int SIG>
 __global__ __launch_bounds__(MCX_BLOCK) void k1_paths(const K1Args a)
 {
-    const int64_t i = (int64_t)blockIdx.x * MCX_BLOCK + threadIdx.x;
-    if (i >= a.n) return;
-    double reg[2 * NSLOT];
-    sim_init_state<NSLOT, SIG>(a, reg);
-    for (int t = 0; t < a.n_initial_store; ++t) sim_store_state<NSLOT, SIG>(a, t, i, reg);
-    const uint64_t path = a.path_offset + (uint64_t)i;
+    constexpr int PPL = INJECT ? 1 : MCX_K1_PPL;
+    const int64_t tid = (int64_t)blockIdx.x * MCX_BLOCK + threadIdx.x;
+    const int64_t half = (int64_t)gridDim.x * MCX_BLOCK;          // lane handles paths tid + q*half
+    if (tid >= a.n) return;
+    double reg[PPL][2 * NSLOT];
+    int64_t idx[PPL];
+    bool live[PPL];
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) {
+        idx[q] = tid + q * half;
+        live[q] = idx[q] < a.n;
+        if (!live[q]) idx[q] = a.n - 1;
+        sim_init_state<NSLOT, SIG>(a, reg[q]);
+    }
+    for (int t = 0; t < a.n_initial_store; ++t)
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) if (live[q]) sim_store_state<NSLOT, SIG>(a, t, idx[q], reg[q]);
     for (int k = 0; k < a.n_steps; ++k) {
-        sim_substep<NSLOT, NZ, INJECT, SIG>(a, k, path, i, reg);
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) sim_substep<NSLOT, NZ, INJECT, SIG>(a, k, a.path_offset + (uint64_t)idx[q], idx[q], reg[q]);
         const int st = ldk(&a.steps[k].store_idx);
-        if (st >= 0) sim_store_state<NSLOT, SIG>(a, st, i, reg);
+        if (st >= 0)
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) if (live[q]) sim_store_state<NSLOT, SIG>(a, st, idx[q], reg[q]);
     }
 }
 
 template <int NSLOT, int NZ, int SIG>
 int launch_k1(const K1Args& a, bool inject, hipStream_t s)
 {
-    const int grid = (int)((a.n + MCX_BLOCK - 1) / MCX_BLOCK);
+    const int ppl = inject ? 1 : MCX_K1_PPL;
+    const int grid = (int)((a.n + (int64_t)MCX_BLOCK * ppl - 1) / ((int64_t)MCX_BLOCK * ppl));
     if (inject) hipLaunchKernelGGL((k1_paths<NSLOT, NZ, true, SIG>), dim3(grid), dim3(MCX_BLOCK), 0, s, a);
     else hipLaunchKernelGGL((k1_paths<NSLOT, NZ, false, SIG>), dim3(grid), dim3(MCX_BLOCK), 0, s, a);
     return 0;

@@ -1,0 +1,63 @@
+"""Hull-White 1F has no oracle in the reference (unimportable draft): parity UNPINNED. Anchors instead:
+ (1) fed with Vasicek's own forward curve, theta(t) is constant and HW reproduces the Vasicek paths (same draws);
+ (2) E[exp(-int_0^T r)] reprices the input discount curve; (3) the closed-form bond price is consistent at t = 0."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from mcx.common.enums import SimulationScheme
+from mcx.engine.engine import MonteCarloEngine
+from mcx.models.hull_white import HullWhiteModel
+from mcx.models.vasicek import VasicekModel
+
+A, SIG, THETA, R0 = 0.3, 0.015, 0.05, 0.02
+
+
+def _vasicek_forward(t):
+    e = math.exp(-A * t)
+    return THETA + (R0 - THETA) * e - SIG ** 2 / (2 * A ** 2) * (1 - e) ** 2
+
+
+def _vasicek_forward_dt(t):
+    e = math.exp(-A * t)
+    return -A * (R0 - THETA) * e - SIG ** 2 / A * (1 - e) * e
+
+
+def _hw():
+    ts = np.linspace(0.0, 3.0, 3001)
+    return HullWhiteModel(0.0, R0, [_vasicek_forward(t) for t in ts], [_vasicek_forward_dt(t) for t in ts], A, SIG,
+                          curve_times=ts)
+
+
+@pytest.mark.parametrize("scheme", [SimulationScheme.EULER, SimulationScheme.ANALYTICAL])
+def test_constant_theta_case_is_vasicek(oracle, scheme):
+    hw, va = _hw(), VasicekModel(0.0, R0, THETA, A, SIG)
+    assert abs(hw.compute_theta(1.3) - A * THETA) < 1e-7
+    tl = np.array([0.0, 0.5, 1.0, 2.0])
+    ph = MonteCarloEngine(tl, scheme, hw, 4096, 4, backend=oracle).generate_paths_native().numpy()
+    pv = MonteCarloEngine(tl, scheme, va, 4096, 4, backend=oracle).generate_paths_native().numpy()
+    assert np.allclose(ph, pv, rtol=1e-5, atol=1e-7)
+    r = torch.linspace(-0.02, 0.08, 7, dtype=torch.float64)
+    assert torch.allclose(hw.compute_bond_price(0.5, 2.0, r), va.compute_bond_price(0.5, 2.0, r), rtol=1e-6)
+
+
+def test_reprices_input_curve(oracle):
+    hw = _hw()
+    tl = np.array([0.0, 2.0])
+    p = MonteCarloEngine(tl, SimulationScheme.ANALYTICAL, hw, 1 << 16, 200, backend=oracle).generate_paths_native().numpy()
+    df = np.exp(-p[1, 1])
+    se = df.std(ddof=1) / math.sqrt(df.size)
+    assert abs(df.mean() - hw.discount_curve(2.0)) < 4 * se + 2e-5          # + left-endpoint quadrature bias
+    assert float(hw.compute_bond_price(0.0, 2.0, R0)) == pytest.approx(hw.discount_curve(2.0), rel=1e-12)
+
+
+@pytest.mark.gpu
+def test_hull_white_gpu_vs_oracle(hip, oracle):
+    hw = _hw()
+    tl = np.array([0.0, 0.25, 1.0, 2.5])
+    for scheme in (SimulationScheme.EULER, SimulationScheme.ANALYTICAL):
+        g = MonteCarloEngine(tl, scheme, hw, 8192, 5, backend=hip).generate_paths_native().cpu().numpy()
+        c = MonteCarloEngine(tl, scheme, hw, 8192, 5, backend=oracle).generate_paths_native().numpy()
+        assert np.allclose(g, c, rtol=1e-10, atol=1e-13)
