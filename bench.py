@@ -80,8 +80,8 @@ def main():
     ap.add_argument("--paths", type=int, default=1 << 20, help="main-simulation paths PER GPU")
     ap.add_argument("--presim", type=int, default=131072, help="pre-simulation (LSM) paths PER GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--unfused", action="store_true", help="force K1, K2, K4 as separate launches (materialised tensors)")
-    ap.add_argument("--fused", action="store_true", help="force the single fused launch")
+    ap.add_argument("--plan", default="auto", choices=["auto", "semi", "fused", "unfused"],
+                    help="main-pass execution plan: semi = K1 + one book/metric kernel; fused = one launch; unfused = K1,K2,K4")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -114,37 +114,48 @@ def main():
     # two execution plans exist for the main pass (one fused launch / K1+K2+K4 launches); time both once, keep the faster
     plan_ms = {}
     fused_obj = sc._fused
-    for name, obj in (("fused", fused_obj), ("unfused", None)):
-        if name == "fused" and (obj is None or args.unfused):
+    names = ["semi", "fused", "unfused"]
+    if args.plan != "auto":
+        names = [args.plan]
+
+    def set_plan(name):
+        sc._fused = None if name == "unfused" else fused_obj
+        sc.main_plan = name if name != "unfused" else sc.main_plan
+
+    for name in names:
+        if name != "unfused" and fused_obj is None:
             continue
-        if name == "unfused" and args.fused:
-            continue
-        sc._fused = obj
-        sc.main_pass(paths_buf if obj is None else None)
+        set_plan(name)
+        sc.main_pass(paths_buf if name != "fused" else None)
         barrier()
         t0 = time.perf_counter()
         for _ in range(2):
-            sc.main_pass(paths_buf if obj is None else None)
+            sc.main_pass(paths_buf if name != "fused" else None)
         barrier()
         plan_ms[name] = (time.perf_counter() - t0) / 2 * 1e3
     best = min(plan_ms, key=plan_ms.get)
     if world > 1:      # all ranks must agree
-        flag = torch.tensor([1.0 if best == "fused" else 0.0], device="cuda")
+        flag = torch.tensor([float(names.index(best))], device="cuda")
         dist.broadcast(flag, 0)
-        best = "fused" if flag.item() > 0.5 else "unfused"
-    sc._fused = fused_obj if best == "fused" else None
+        best = names[int(flag.item())]
+    set_plan(best)
     for _ in range(args.warmup):
-        res = sc.main_pass(paths_buf if sc._fused is None else None)
+        res = sc.main_pass(paths_buf if best != "fused" else None)
     # per-kernel device time of the dominant kernel (K1) with HIP events on the launch stream
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
-    fused = sc._fused is not None
+    fused = best == "fused"
     for k in range(args.steps):
         ev[k][0].record()
         if fused:
             res = sc._fused_pass()               # one launch: K1+K2+K4 (+ block merge, record copy, rank gather)
             ev[k][1].record()
+        elif best == "semi":
+            paths = sc._main_engine.generate_paths_native(out=paths_buf)
+            ev[k][1].record()                    # K1 device time; then ONE kernel for book + metrics
+            rec = be.fused_eval_paths(sc._fused, paths)
+            res = sc._finish_fused_records(rec)
         else:
             paths = sc._main_engine.generate_paths_native(out=paths_buf)
             ev[k][1].record()
@@ -174,7 +185,7 @@ def main():
             "config": {"workload": "Vasicek+CIR++ (rho=0.5) payer IRS CVA, Euler, 51 dates x 5 sub-steps (SURVEY §8d config 3)",
                        "paths_per_gpu": n_local, "steps_per_path": S, "state_dim": D, "stored_dates": T,
                        "exposure_dates": E, "presim_paths_per_gpu": args.presim, "parallelism": f"paths x{world}",
-                       "execution_plan": "fused" if fused else "unfused", "plan_probe_ms": plan_ms},
+                       "execution_plan": best, "plan_probe_ms": plan_ms},
             "roofline": {"bound": "hbm", "kernel": "kf_fused<2,2> (K1+K2+K4 in one launch)" if fused else "k1_paths<2,2> (Philox+Box-Muller+Cholesky+Euler)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel_ms": k1_ms, "algorithmic_bytes_per_launch": k1_bytes,

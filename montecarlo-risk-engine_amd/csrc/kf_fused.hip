@@ -65,7 +65,7 @@ __device__ __forceinline__ double f_atom(const FAtom& a, const double (&reg)[NRE
 #pragma unroll
     for (int q = 0; q < NREG; ++q) x = (a.reg == q) ? reg[q] : x;
     double v = fma(a.d, x, a.a);
-    if (a.b != 0.0) v = fma(a.b, exp(fma(a.c1, x, a.c0)), v);
+    if (a.b != 0.0) v = fma(a.b, mcx_exp(fma(a.c1, x, a.c0)), v);
     return v;
 }
 
@@ -76,8 +76,6 @@ __device__ __forceinline__ double f_poly(const double* __restrict__ c, int K, do
     for (int k = 0; k < K; ++k) { v = fma(c[k], xp, v); xp *= x; }
     return v;
 }
-
-__device__ __forceinline__ double f_norm_cdf(double x) { return 0.5 * (1.0 + erf(x * 0.70710678118654752440)); }
 
 // LDS record area: shift[n_rec] | acc[4 waves][n_rec][2]
 __device__ __forceinline__ void f_record(double v, bool live, int rec, int n_rec, bool first_tile, double* __restrict__ lds)
@@ -100,7 +98,7 @@ __device__ __forceinline__ void f_record(double v, bool live, int rec, int n_rec
 // The book's events + metric operations of ONE timeline date for one lane.  The date's program chunk sits in the wave's
 // private LDS slot (`chunk`): all 64 lanes read the same addresses (LDS broadcast, no bank conflicts), so walking the
 // program costs ds_read latency (~64-128 clk) instead of a chain of dependent L2 round trips per record.
-template <int NSLOT, int SIG, int NNS, int NSTA>
+template <int NSLOT, int SIG, int NNS, int NSTA, bool STORE>
 __device__ __forceinline__ void kf_on_date(const FusedArgs& a, int t, int64_t i, bool live, bool first_tile, double* __restrict__ lds,
                                            const unsigned char* __restrict__ chunk, const double (&reg)[2 * NSLOT],
                                            double (&cfs)[NNS], double (&cva)[NNS], int (&est)[NSTA])
@@ -108,7 +106,7 @@ __device__ __forceinline__ void kf_on_date(const FusedArgs& a, int t, int64_t i,
     constexpr int NREG = 2 * NSLOT;
     const K1Args& k = a.k1;
     const int n_rec = a.n_rec;
-    if (k.paths && live) sim_store_state<NSLOT, SIG>(k, t, i, reg);
+    if (STORE && k.paths && live) sim_store_state<NSLOT, SIG>(k, t, i, reg);
     const ChunkHeader hd = *(const ChunkHeader*)chunk;
     const FEvent* __restrict__ evs = (const FEvent*)(chunk + sizeof(ChunkHeader));
     const FTerm* __restrict__ terms = (const FTerm*)(evs + hd.n_ev);
@@ -157,16 +155,6 @@ __device__ __forceinline__ void kf_on_date(const FusedArgs& a, int t, int64_t i,
                 for (int w = 0; w < NSTA; ++w) s = (e.sidx == w) ? est[w] : s;
                 const double x = f_atom<NREG>(e.x, reg);
                 v = (e.coeff_off >= 0 ? f_poly(a.coeffs + e.coeff_off + s * a.n_basis, a.n_basis, x) : 0.0) * inv_num;
-            } else if (e.aux[2] > 0.0) {
-                const double spot = f_atom<NREG>(e.x, reg);
-                const double sig = e.aux[0], rate = e.aux[1], tau = e.aux[2], Kx = e.strike;
-                const double sq = sqrt(tau);
-                const double d1 = (log(spot / Kx) + (rate + 0.5 * sig * sig) * tau) / (sig * sq);
-                const double d2 = d1 - sig * sq;
-                const double df = exp(-rate * tau);
-                const double price = e.sign > 0.0 ? spot * f_norm_cdf(d1) - Kx * df * f_norm_cdf(d2)
-                                                  : Kx * df * f_norm_cdf(-d2) - spot * f_norm_cdf(-d1);
-                v = price * inv_num;
             }
 #pragma unroll
             for (int w = 0; w < NNS; ++w) e_ns[w] += (NNS == 1 || e.ns == w) ? v : 0.0;
@@ -219,7 +207,9 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // NPF = 1 KiB pieces of the NEXT date's program chunk each wave prefetches into VGPRs (one coalesced global_load_dwordx4
 // per piece, issued before the sub-steps that lead to that date, written to the wave's LDS slot just before use: the HBM/L2
 // latency hides under ~5 sub-steps of RNG + SDE work).  NPF = 0: chunks larger than 2 KiB are copied at use.
-template <int NSLOT, int NZ, bool INJECT, int SIG, int NNS, int NST, int NPF>
+// SIMULATE = false: the same event/metric program runs on a paths tensor produced earlier by K1 (`k.paths` is then the
+// INPUT [date][state][path]): one pass over the paths replaces K2 + K4 and writes no exposure matrix unless asked to.
+template <int NSLOT, int NZ, bool INJECT, int SIG, int NNS, int NST, int NPF, bool SIMULATE>
 __global__ __launch_bounds__(MCX_BLOCK) MCX_KF_ATTR void kf_fused(const FusedArgs a)
 {
     constexpr int NREG = 2 * NSLOT;
@@ -275,22 +265,47 @@ __global__ __launch_bounds__(MCX_BLOCK) MCX_KF_ATTR void kf_fused(const FusedArg
 
         int next_t = 0;                                    // timeline dates are visited in increasing order, each once
         prefetch(0);
-        for (int t = 0; t < k.n_initial_store; ++t) {
-            stage(t);
-            prefetch(t + 1);
-            kf_on_date<NSLOT, SIG, NNS, NSTA>(a, t, i, live, first_tile, lds, slot, reg, cfs, cva, est);
-            next_t = t + 1;
-        }
-        const uint64_t path = k.path_offset + (uint64_t)i;
+        if (SIMULATE) {
+            for (int t = 0; t < k.n_initial_store; ++t) {
+                stage(t);
+                prefetch(t + 1);
+                kf_on_date<NSLOT, SIG, NNS, NSTA, true>(a, t, i, live, first_tile, lds, slot, reg, cfs, cva, est);
+                next_t = t + 1;
+            }
+            const uint64_t path = k.path_offset + (uint64_t)i;
 #pragma unroll 1
-        for (int step = 0; step < k.n_steps; ++step) {
-            sim_substep<NSLOT, NZ, INJECT, SIG>(k, step, path, i, reg);
-            const int st = ldk(&k.steps[step].store_idx);
-            if (st >= 0) {
-                stage(st);
-                prefetch(st + 1);
-                kf_on_date<NSLOT, SIG, NNS, NSTA>(a, st, i, live, first_tile, lds, slot, reg, cfs, cva, est);
-                next_t = st + 1;
+            for (int step = 0; step < k.n_steps; ++step) {
+                sim_substep<NSLOT, NZ, INJECT, SIG>(k, step, path, i, reg);
+                const int st = ldk(&k.steps[step].store_idx);
+                if (st >= 0) {
+                    stage(st);
+                    prefetch(st + 1);
+                    kf_on_date<NSLOT, SIG, NNS, NSTA, true>(a, st, i, live, first_tile, lds, slot, reg, cfs, cva, est);
+                    next_t = st + 1;
+                }
+            }
+        } else {
+            const int D = k.n_state;
+            double nxt[NREG];
+            auto load_row = [&](int t, double (&dst)[NREG]) {
+#pragma unroll
+                for (int s = 0; s < NSLOT; ++s) {
+                    const bool bs = sig_kind(SIG, s) >= 0 ? sig_is_bs(SIG, s) : (k.slots[s].kind == MCX_MODEL_BS);
+                    const int c = k.slots[s].state_off;
+                    dst[2 * s] = k.paths[((int64_t)t * D + c) * k.ld + i];
+                    dst[2 * s + 1] = bs ? 0.0 : k.paths[((int64_t)t * D + c + 1) * k.ld + i];
+                }
+            };
+            load_row(0, nxt);
+#pragma unroll 1
+            for (int t = 0; t < a.n_dates; ++t) {
+#pragma unroll
+                for (int q = 0; q < NREG; ++q) reg[q] = nxt[q];
+                if (t + 1 < a.n_dates) load_row(t + 1, nxt);      // next date's state streams in while this date's ops run
+                stage(t);
+                prefetch(t + 1);
+                kf_on_date<NSLOT, SIG, NNS, NSTA, false>(a, t, i, live, first_tile, lds, slot, reg, cfs, cva, est);
+                next_t = t + 1;
             }
         }
         (void)next_t;
@@ -313,34 +328,49 @@ __global__ __launch_bounds__(MCX_BLOCK) MCX_KF_ATTR void kf_fused(const FusedArg
     }
 }
 
-// merge per-block records (Chan, Golub, LeVeque pairwise update) -> out[r] = (n, mean, 0, M2)
-__global__ void kf_merge(const double* __restrict__ partials, int n_rec, int n_blocks, mcx_acc* __restrict__ out)
+// merge per-block records (Chan, Golub, LeVeque pairwise update) -> out[r] = (n, mean, 0, M2).
+// One 256-thread block per record: every thread folds a strided subset of the block records (independent loads in
+// flight), the 256 partial triples are then combined through LDS.  (A one-thread serial merge over 2048 dependent loads
+// took 0.8 ms — a quarter of the whole pass.)
+__device__ __forceinline__ void chan_merge(double& N, double& mean, double& M2, double n, double m, double q)
 {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_rec) return;
+    if (n <= 0.0) return;
+    if (N == 0.0) { N = n; mean = m; M2 = q; return; }
+    const double delta = m - mean, tot = N + n;
+    mean += delta * n / tot;
+    M2 += q + delta * delta * N * n / tot;
+    N = tot;
+}
+
+__global__ __launch_bounds__(MCX_BLOCK) void kf_merge(const double* __restrict__ partials, int n_rec, int n_blocks, mcx_acc* __restrict__ out)
+{
+    const int r = blockIdx.x;
+    __shared__ double sN[MCX_BLOCK], sM[MCX_BLOCK], sQ[MCX_BLOCK];
     double N = 0.0, mean = 0.0, M2 = 0.0;
-    for (int b = 0; b < n_blocks; ++b) {
+    for (int b = threadIdx.x; b < n_blocks; b += MCX_BLOCK) {
         const double* p = partials + ((int64_t)b * n_rec + r) * 4;
         const double n = p[0];
-        if (n <= 0.0) continue;
-        const double m = p[1] + p[2] / n;
-        const double q = fmax(p[3] - p[2] * p[2] / n, 0.0);
-        if (N == 0.0) { N = n; mean = m; M2 = q; }
-        else {
-            const double delta = m - mean, tot = N + n;
-            mean += delta * n / tot;
-            M2 += q + delta * delta * N * n / tot;
-            N = tot;
-        }
+        if (n > 0.0) chan_merge(N, mean, M2, n, p[1] + p[2] / n, fmax(p[3] - p[2] * p[2] / n, 0.0));
     }
-    out[r].n = N; out[r].shift = mean; out[r].s1 = 0.0; out[r].s2 = M2;
+    sN[threadIdx.x] = N; sM[threadIdx.x] = mean; sQ[threadIdx.x] = M2;
+    __syncthreads();
+    for (int stride = MCX_BLOCK / 2; stride > 0; stride >>= 1) {
+        if ((int)threadIdx.x < stride) {
+            double a = sN[threadIdx.x], b = sM[threadIdx.x], c = sQ[threadIdx.x];
+            chan_merge(a, b, c, sN[threadIdx.x + stride], sM[threadIdx.x + stride], sQ[threadIdx.x + stride]);
+            sN[threadIdx.x] = a; sM[threadIdx.x] = b; sQ[threadIdx.x] = c;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[r].n = sN[0]; out[r].shift = sM[0]; out[r].s1 = 0.0; out[r].s2 = sQ[0]; }
 }
 
 template <int NSLOT, int NZ, int SIG>
-void launch_kf(const FusedArgs& a, int grid, size_t lds, int npf, bool inject, hipStream_t s)
+void launch_kf(const FusedArgs& a, int grid, size_t lds, int npf, bool inject, bool simulate, hipStream_t s)
 {
     const bool one_ns = a.n_ns == 1, no_state = a.n_stateful == 0;
-#define MCX_KF(INJ, NNS, NST, NPF) hipLaunchKernelGGL((kf_fused<NSLOT, NZ, INJ, SIG, NNS, NST, NPF>), dim3(grid), dim3(MCX_BLOCK), lds, s, a)
+#define MCX_KF(INJ, NNS, NST, NPF) do { if (simulate) hipLaunchKernelGGL((kf_fused<NSLOT, NZ, INJ, SIG, NNS, NST, NPF, true>), dim3(grid), dim3(MCX_BLOCK), lds, s, a); \
+        else if (!INJ) hipLaunchKernelGGL((kf_fused<NSLOT, NZ, false, SIG, NNS, NST, NPF, false>), dim3(grid), dim3(MCX_BLOCK), lds, s, a); } while (0)
 #define MCX_KF_NPF(INJ, NNS, NST) do { if (npf == 1) MCX_KF(INJ, NNS, NST, 1); else if (npf == 2) MCX_KF(INJ, NNS, NST, 2); else MCX_KF(INJ, NNS, NST, 0); } while (0)
     if (inject) {
         if (one_ns && no_state) MCX_KF_NPF(true, 1, 0);
@@ -496,6 +526,8 @@ extern "C" int mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_boo
     std::vector<unsigned char> prog;
     std::vector<int32_t> date_off(T + 1, 0);
     int max_chunk = 0;
+    bool bs_exposure = false;
+    for (int t = 0; t < T; ++t) for (const FEvent& e : by_date[t]) if (e.kind == MCX_EV_EXPO_BS) bs_exposure = true;
     for (int t = 0; t < T; ++t) {
         date_off[t] = (int32_t)prog.size();
         ChunkHeader hd;
@@ -514,6 +546,7 @@ extern "C" int mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_boo
         max_chunk = std::max(max_chunk, (int)padded);
     }
     date_off[T] = (int32_t)prog.size();
+    if (bs_exposure) { delete f; MCX_FAIL(h, MCX_E_NOT_FUSABLE, "not fusable: analytic Black-Scholes exposures are evaluated by the book kernel (K2)"); }
     // LDS budget: 4 wave slots + the record area must fit comfortably (several blocks per CU)
     f->npf = max_chunk <= 1024 ? 1 : (max_chunk <= 2048 ? 2 : 0);
     f->chunk_cap = f->npf > 0 ? f->npf * 1024 : ((max_chunk + 255) & ~255);
@@ -541,9 +574,9 @@ extern "C" int mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_boo
     return 0;
 }
 
-extern "C" int mcx_fused_run(mcx_handle* h, const mcx_fused* f, uint64_t seed, uint64_t path_offset, int64_t n_paths,
-                             double* d_paths, int64_t ld, double* d_cfs, double* d_expo, int64_t ld_out,
-                             const double* d_inject_z, const double* d_inject_u, mcx_acc* h_out, void* stream)
+static int fused_run_impl(mcx_handle* h, const mcx_fused* f, bool simulate, uint64_t seed, uint64_t path_offset, int64_t n_paths,
+                          double* d_paths, int64_t ld, double* d_cfs, double* d_expo, int64_t ld_out,
+                          const double* d_inject_z, const double* d_inject_u, mcx_acc* h_out, void* stream)
 {
     if (!h || !f || !h_out) return -1;
     if (n_paths <= 0) { memset(h_out, 0, sizeof(mcx_acc) * (size_t)f->n_rec); return 0; }
@@ -552,6 +585,7 @@ extern "C" int mcx_fused_run(mcx_handle* h, const mcx_fused* f, uint64_t seed, u
     if ((size_t)f->n_rec * sizeof(mcx_acc) > h->pinned_bytes) MCX_FAIL(h, -2, "mcx_fused_run: too many records");
     const mcx_sim_desc& sd = f->sim->desc;
     if (sd.n_uniform && d_inject_z && !d_inject_u) MCX_FAIL(h, -3, "mcx_fused_run: inject_u required with inject_z under QE");
+    if (!simulate && (!d_paths || ld < n_paths)) MCX_FAIL(h, -2, "mcx_fused_eval_paths: a paths tensor with ld >= n_paths is required");
     FusedArgs a;
     memset(&a, 0, sizeof(a));
     mcx_fill_k1_args(f->sim, seed, path_offset, n_paths, ld > 0 ? ld : n_paths, d_paths, d_inject_z, d_inject_u, &a.k1);
@@ -569,29 +603,42 @@ extern "C" int mcx_fused_run(mcx_handle* h, const mcx_fused* f, uint64_t seed, u
     hipStream_t s = (hipStream_t)stream;
     const bool inj = d_inject_z != nullptr;
     switch (mcx_sim_signature(sd)) {
-    case SIG_VAS_CIR_E: launch_kf<2, 2, SIG_VAS_CIR_E>(a, grid, lds, f->npf, inj, s); break;
-    case SIG_BS_A: launch_kf<1, 1, SIG_BS_A>(a, grid, lds, f->npf, inj, s); break;
-    case SIG_BS_E: launch_kf<1, 1, SIG_BS_E>(a, grid, lds, f->npf, inj, s); break;
-    case SIG_HESTON_QE: launch_kf<1, 2, SIG_HESTON_QE>(a, grid, lds, f->npf, inj, s); break;
-    case SIG_HESTON_E: launch_kf<1, 2, SIG_HESTON_E>(a, grid, lds, f->npf, inj, s); break;
-    case SIG_VAS_E: launch_kf<1, 1, SIG_VAS_E>(a, grid, lds, f->npf, inj, s); break;
-    case SIG_VAS_A: launch_kf<1, 1, SIG_VAS_A>(a, grid, lds, f->npf, inj, s); break;
-    case SIG_BS_VAS_CIRDET_E: launch_kf<3, 3, SIG_BS_VAS_CIRDET_E>(a, grid, lds, f->npf, inj, s); break;
+    case SIG_VAS_CIR_E: launch_kf<2, 2, SIG_VAS_CIR_E>(a, grid, lds, f->npf, inj, simulate, s); break;
+    case SIG_BS_A: launch_kf<1, 1, SIG_BS_A>(a, grid, lds, f->npf, inj, simulate, s); break;
+    case SIG_BS_E: launch_kf<1, 1, SIG_BS_E>(a, grid, lds, f->npf, inj, simulate, s); break;
+    case SIG_HESTON_QE: launch_kf<1, 2, SIG_HESTON_QE>(a, grid, lds, f->npf, inj, simulate, s); break;
+    case SIG_HESTON_E: launch_kf<1, 2, SIG_HESTON_E>(a, grid, lds, f->npf, inj, simulate, s); break;
+    case SIG_VAS_E: launch_kf<1, 1, SIG_VAS_E>(a, grid, lds, f->npf, inj, simulate, s); break;
+    case SIG_VAS_A: launch_kf<1, 1, SIG_VAS_A>(a, grid, lds, f->npf, inj, simulate, s); break;
+    case SIG_BS_VAS_CIRDET_E: launch_kf<3, 3, SIG_BS_VAS_CIRDET_E>(a, grid, lds, f->npf, inj, simulate, s); break;
     default:
         switch (sd.n_slots * 16 + sd.n_z) {
-        case 1 * 16 + 1: launch_kf<1, 1, SIG_GENERIC>(a, grid, lds, f->npf, inj, s); break;
-        case 1 * 16 + 2: launch_kf<1, 2, SIG_GENERIC>(a, grid, lds, f->npf, inj, s); break;
-        case 2 * 16 + 2: launch_kf<2, 2, SIG_GENERIC>(a, grid, lds, f->npf, inj, s); break;
-        case 3 * 16 + 3: launch_kf<3, 3, SIG_GENERIC>(a, grid, lds, f->npf, inj, s); break;
-        case 4 * 16 + 4: launch_kf<4, 4, SIG_GENERIC>(a, grid, lds, f->npf, inj, s); break;
+        case 1 * 16 + 1: launch_kf<1, 1, SIG_GENERIC>(a, grid, lds, f->npf, inj, simulate, s); break;
+        case 1 * 16 + 2: launch_kf<1, 2, SIG_GENERIC>(a, grid, lds, f->npf, inj, simulate, s); break;
+        case 2 * 16 + 2: launch_kf<2, 2, SIG_GENERIC>(a, grid, lds, f->npf, inj, simulate, s); break;
+        case 3 * 16 + 3: launch_kf<3, 3, SIG_GENERIC>(a, grid, lds, f->npf, inj, simulate, s); break;
+        case 4 * 16 + 4: launch_kf<4, 4, SIG_GENERIC>(a, grid, lds, f->npf, inj, simulate, s); break;
         default: MCX_FAIL(h, MCX_E_NOT_FUSABLE, "not fusable: (slots=%d, z=%d) has no fused instantiation", sd.n_slots, sd.n_z);
         }
     }
     MCX_HIP(h, hipGetLastError());
-    hipLaunchKernelGGL(kf_merge, dim3((f->n_rec + 63) / 64), dim3(64), 0, s, f->d_partials, f->n_rec, grid, f->d_out);
+    hipLaunchKernelGGL(kf_merge, dim3(f->n_rec), dim3(MCX_BLOCK), 0, s, f->d_partials, f->n_rec, grid, f->d_out);
     MCX_HIP(h, hipGetLastError());
     MCX_HIP(h, hipMemcpyAsync(h->h_pinned, f->d_out, sizeof(mcx_acc) * (size_t)f->n_rec, hipMemcpyDeviceToHost, s));
     MCX_HIP(h, hipStreamSynchronize(s));
     memcpy(h_out, h->h_pinned, sizeof(mcx_acc) * (size_t)f->n_rec);
     return 0;
+}
+
+extern "C" int mcx_fused_run(mcx_handle* h, const mcx_fused* f, uint64_t seed, uint64_t path_offset, int64_t n_paths,
+                             double* d_paths, int64_t ld, double* d_cfs, double* d_expo, int64_t ld_out,
+                             const double* d_inject_z, const double* d_inject_u, mcx_acc* h_out, void* stream)
+{
+    return fused_run_impl(h, f, true, seed, path_offset, n_paths, d_paths, ld, d_cfs, d_expo, ld_out, d_inject_z, d_inject_u, h_out, stream);
+}
+
+extern "C" int mcx_fused_eval_paths(mcx_handle* h, const mcx_fused* f, const double* d_paths, int64_t n_paths, int64_t ld,
+                                    double* d_cfs, double* d_expo, int64_t ld_out, mcx_acc* h_out, void* stream)
+{
+    return fused_run_impl(h, f, false, 0, 0, n_paths, const_cast<double*>(d_paths), ld, d_cfs, d_expo, ld_out, nullptr, nullptr, h_out, stream);
 }

@@ -64,9 +64,9 @@ __device__ __forceinline__ void draw_pair(uint64_t seed, uint64_t path, uint32_t
     philox4x32_10((uint32_t)path, (uint32_t)(path >> 32), step, draw, (uint32_t)seed, (uint32_t)(seed >> 32), w0, w1, w2, w3);
     ua = u53(w0, w1);
     const double ub = u53(w2, w3);
-    const double r = sqrt(-2.0 * log(ua));
+    const double r = sqrt(-2.0 * mcx_log(ua));
     double s, c;
-    sincospi(2.0 * ub, &s, &c);
+    mcx_sincos2pi(ub, s, c);
     z0 = r * c;
     z1 = r * s;
 }
@@ -90,7 +90,7 @@ __device__ __forceinline__ void step_slot(const mcx_slot& sl, int scheme_rt, int
     switch (KIND >= 0 ? KIND : sl.kind) {
     case MCX_MODEL_BS:
         if (scheme == MCX_SCHEME_ANALYTICAL) {
-            s0 = s0 * exp(ldk(aux + 0) + (zc0 - ldk(aux + 1)));                       // black_scholes.py:61-67
+            s0 = s0 * mcx_exp(ldk(aux + 0) + (zc0 - ldk(aux + 1)));                       // black_scholes.py:61-67
         } else {
             s0 = s0 + (p[2] * s0 * dt + p[1] * s0 * sq * zc0);           // black_scholes.py:79-85
         }
@@ -144,7 +144,7 @@ __device__ __forceinline__ void step_slot(const mcx_slot& sl, int scheme_rt, int
             const double beta = (1.0 - pp) / (m + eps);
             const double omu = fmax(1.0 - u, eps);
             const double omp = fmax(1.0 - pp, eps);
-            const double v_tail = log(omp / omu) / (beta + eps);
+            const double v_tail = mcx_log(omp / omu) / (beta + eps);
             const double v2 = degree_of_truth(u - pp, fuzzy, 0.3) * v_tail;
             const double w = degree_of_truth(psi - 1.5, fuzzy, 0.5);
             const double vn = (1.0 - w) * v1 + w * v2;

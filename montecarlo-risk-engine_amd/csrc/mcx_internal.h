@@ -119,12 +119,14 @@ __device__ __forceinline__ T ldk_struct(const T* p)
     return out;
 }
 
+#include "mcx_math.h"
+
 __device__ __forceinline__ double dev_atom(const DevAtom& a, const double* __restrict__ paths, int64_t D, int64_t ld, int64_t i)
 {
     double x = 0.0;
     if (a.col >= 0) x = paths[((int64_t)a.t_idx * D + a.col) * ld + i];
     double v = fma(a.d, x, a.a);
-    if (a.b != 0.0) v = fma(a.b, exp(fma(a.c1, x, a.c0)), v);
+    if (a.b != 0.0) v = fma(a.b, mcx_exp(fma(a.c1, x, a.c0)), v);
     return v;
 }
 

@@ -1,0 +1,65 @@
+// mcx_math.h — lean float64 exp / log / sincos(2*pi*u) for the path kernels (gfx950).
+//
+// Why not ocml's exp/log/sincospi: a v_fma_f64 can take only ONE scalar/literal operand, so the backend materialises every
+// polynomial coefficient of an inlined libm routine in a VGPR pair and hoists it out of the sub-step loop — log + sincospi
+// + exp pin ~80-120 VGPRs for the whole kernel (measured: the fused kernel sat at 160-200 VGPRs = 2-3 waves/SIMD with a
+// tiny live state).  Here the coefficients come from a constant-address-space table: scalar loads -> SGPRs -> the single
+// scalar operand of each Horner FMA.  Accuracy: <= ~2 ulp on the ranges used (u in (0,1), |x| < 700), checked against the
+// CPU oracle (glibc libm) in tests at 1e-11 relative on whole paths.
+#pragma once
+// (included from mcx_internal.h right after ldk())
+
+__device__ const double MCX_EXP_C[14] = {1.00000000000000000e+00, 1.00000000000000000e+00, 5.00000000000000000e-01, 1.66666666666666657e-01, 4.16666666666666644e-02, 8.33333333333333322e-03, 1.38888888888888894e-03, 1.98412698412698413e-04, 2.48015873015873016e-05, 2.75573192239858925e-06, 2.75573192239858883e-07, 2.50521083854417202e-08, 2.08767569878681002e-09, 1.60590438368216133e-10};
+__device__ const double MCX_SIN_C[10] = {3.14159265358979312e+00, -5.16771278004997026e+00, 2.55016403987734552e+00, -5.99264529320792105e-01, 8.21458866111282326e-02, -7.37043094571435044e-03, 4.66302805767612554e-04, -2.19153534478302173e-05, 7.95205400147551261e-07, -2.29484289972698730e-08};   // sin(pi r) = sum_k S_k r^(2k+1)
+__device__ const double MCX_COS_C[10] = {1.00000000000000000e+00, -4.93480220054467900e+00, 4.05871212641676848e+00, -1.33526276885458950e+00, 2.35330630358893206e-01, -2.58068913900140612e-02, 1.92957430940392314e-03, -1.04638104924845705e-04, 4.30306958703294729e-06, -1.38789524622137714e-07};   // cos(pi r) = sum_k C_k r^(2k)
+__device__ const double MCX_LOG_C[7] = {6.666666666666735130e-01, 3.999999999940941908e-01, 2.857142874366239149e-01, 2.222219843214978396e-01, 1.818357216161805012e-01, 1.531383769920937332e-01, 1.479819860511658591e-01};    // fdlibm e_log.c Lg1..Lg7
+
+// exp(x), |x| <~ 708.  x = k ln2 + r, |r| <= ln2/2; Taylor degree 13 in r; scale by 2^k.
+__device__ __forceinline__ double mcx_exp(double x)
+{
+    const double k = rint(x * 1.4426950408889634074);
+    double r = fma(k, -6.93147180369123816490e-01, x);       // ln2_hi
+    r = fma(k, -1.90821492927058770002e-10, r);              // ln2_lo
+    double p = ldk(MCX_EXP_C + 13);
+#pragma unroll
+    for (int j = 12; j >= 0; --j) p = fma(p, r, ldk(MCX_EXP_C + j));
+    return ldexp(p, (int)k);
+}
+
+// log(x) for normal x > 0 (fdlibm __ieee754_log without the special cases)
+__device__ __forceinline__ double mcx_log(double x)
+{
+    int e;
+    double m = frexp(x, &e);                                  // m in [0.5, 1)
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? m + m : m;                                       // m in [sqrt(1/2), sqrt(2))
+    e -= lo ? 1 : 0;
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    double R = ldk(MCX_LOG_C + 6);
+#pragma unroll
+    for (int j = 5; j >= 0; --j) R = fma(R, z, ldk(MCX_LOG_C + j));
+    R *= z;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)e;
+    return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+}
+
+// (sin, cos)(2 pi u) for u in [0, 1): x = 2u in units of pi; n = nearest multiple of 1/2, r = x - n/2 in [-1/4, 1/4]
+__device__ __forceinline__ void mcx_sincos2pi(double u, double& s, double& c)
+{
+    const double x = u + u;
+    const double n = rint(x + x);
+    const double r = fma(n, -0.5, x);
+    const double t = r * r;
+    double ps = ldk(MCX_SIN_C + 9), pc = ldk(MCX_COS_C + 9);
+#pragma unroll
+    for (int j = 8; j >= 0; --j) { ps = fma(ps, t, ldk(MCX_SIN_C + j)); pc = fma(pc, t, ldk(MCX_COS_C + j)); }
+    ps *= r;
+    const int q = (int)n;                                     // quadrant: angle = q*pi/2 + pi*r
+    const bool swap = q & 1;
+    const double a = swap ? pc : ps, b = swap ? ps : pc;      // sin(theta), cos(theta) up to signs
+    s = (q & 2) ? -a : a;
+    c = ((q + 1) & 2) ? -b : b;
+}

@@ -22,7 +22,7 @@ _EXPORTS = [
     "mcx_sim_create", "mcx_sim_destroy", "mcx_generate_paths",
     "mcx_book_create", "mcx_book_destroy", "mcx_book_set_coeffs", "mcx_eval_book", "mcx_resolve_atoms",
     "mcx_lsm_stats", "mcx_lsm_step",
-    "mcx_tangent_european", "mcx_fused_create", "mcx_fused_destroy", "mcx_fused_num_records", "mcx_fused_run",
+    "mcx_tangent_european", "mcx_fused_create", "mcx_fused_destroy", "mcx_fused_num_records", "mcx_fused_run", "mcx_fused_eval_paths",
     "mcx_reduce_vector", "mcx_reduce_profiles", "mcx_reduce_cva", "mcx_unsecured", "mcx_select_hist",
 ]
 
@@ -181,6 +181,14 @@ class HipBackend:
         self._check(self.lib.mcx_fused_run(
             self.h, fused.ptr, C.c_uint64(seed), C.c_uint64(path_offset), C.c_int64(n_paths), dp(paths), C.c_int64(n_paths),
             dp(cfs), dp(expo), C.c_int64(n_paths), dp(inject_z), dp(inject_u), _abi.ptr(out), self._stream()), "mcx_fused_run")
+        return out
+
+    def fused_eval_paths(self, fused, paths: torch.Tensor, cfs=None, expo=None) -> np.ndarray:
+        out = np.zeros(fused.plan.n_records, dtype=_abi.ACC_DTYPE)
+        n = paths.shape[2]
+        dp = lambda t: _vp(t.data_ptr() if t is not None else 0)
+        self._check(self.lib.mcx_fused_eval_paths(self.h, fused.ptr, dp(paths), C.c_int64(n), C.c_int64(n), dp(cfs), dp(expo),
+                                                  C.c_int64(n), _abi.ptr(out), self._stream()), "mcx_fused_eval_paths")
         return out
 
     # ---- tangents ------------------------------------------------------------------------------------------------

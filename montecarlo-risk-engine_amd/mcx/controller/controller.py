@@ -95,7 +95,10 @@ class SimulationController:
         self.use_mfma = use_mfma
         # the reference accumulates LSM cashflows in a float32 cache (controller.py:312-330); reproduce it for parity
         self.reference_float32_cf_cache = True
-        self.allow_fused = True      # one-launch main pass (csrc/kf_fused.hip) when the book is fusable
+        self.allow_fused = True      # fused event/metric program (csrc/kf_fused.hip) when the book is fusable
+        # main-pass execution plan when fusable: "semi" = K1 writes the paths tensor, ONE kernel evaluates book + metrics
+        # from it; "fused" = a single launch, nothing materialised; (None/unfusable: K1, K2, K4 as separate launches)
+        self.main_plan = "semi"
         self.materialize = False     # also write paths / cashflows / exposures in the fused pass (inspection, tests)
         self._backend = backend
         for i, p in enumerate(products):
@@ -516,14 +519,24 @@ class SimulationController:
     def _fused_pass(self, paths_out=None):
         be, f, eng = self.backend, self._fused, self._main_engine
         n = eng.num_paths
+        semi = self.main_plan == "semi" and hasattr(be, "fused_eval_paths")
         need_expo = self._fused_needs_expo or self.materialize
         paths = (paths_out if paths_out is not None else be.empty(self.sim_plan.n_dates, self.sim_plan.n_state, n)) \
-            if (self.materialize or paths_out is not None) else None
+            if (self.materialize or paths_out is not None or semi) else None
         bp = self.book_plan
         expo = be.empty(bp.n_netting_sets, bp.n_expo_rows, n) if (need_expo and bp.desc.want_expo) else None
         cfs = be.empty(bp.n_netting_sets, n) if (self.materialize and bp.desc.want_cfs) else None
-        rec = be.fused_run(f, eng.seed, eng.path_offset, n, paths=paths, cfs=cfs, expo=expo,
-                           inject_z=eng.inject_z, inject_u=eng.inject_u)
+        if semi:
+            eng.generate_paths_native(out=paths)
+            rec = be.fused_eval_paths(f, paths, cfs=cfs, expo=expo)
+        else:
+            rec = be.fused_run(f, eng.seed, eng.path_offset, n, paths=paths, cfs=cfs, expo=expo,
+                               inject_z=eng.inject_z, inject_u=eng.inject_u)
+        self.last_state.update(paths=paths, cfs=cfs, expo=expo)
+        return self._finish_fused_records(rec, cfs, expo, paths)
+
+    def _finish_fused_records(self, rec, cfs=None, expo=None, paths=None):
+        f = self._fused
         g = self._shard.all_gather_np(rec.view(np.float64).reshape(-1, 4))        # [world][n_rec][4]
         fused_records = []
         for ns_i, lay in enumerate(f.plan.layout):
@@ -536,7 +549,6 @@ class SimulationController:
             if lay["cva"] is not None:
                 fr["cva"] = g[:, lay["cva"]]
             fused_records.append(fr)
-        self.last_state.update(paths=paths, cfs=cfs, expo=expo)
         return self._evaluate_all(self._shard, cfs, expo, paths, fused_records)
 
     def main_pass(self, paths_out=None):

@@ -172,9 +172,13 @@ class OracleBackend:
         return f
 
     def fused_run(self, fused, seed, path_offset, n_paths, paths=None, cfs=None, expo=None, inject_z=None, inject_u=None):
+        p = self.generate_paths(fused.sim, seed, path_offset, n_paths, inject_z, inject_u, out=paths)
+        return self.fused_eval_paths(fused, p, cfs=cfs, expo=expo)
+
+    def fused_eval_paths(self, fused, paths, cfs=None, expo=None):
         from mcx.plan import UnsecuredSpec
         plan = fused.plan
-        p = self.generate_paths(fused.sim, seed, path_offset, n_paths, inject_z, inject_u, out=paths)
+        p = paths
         c, e = self.eval_book(fused.book, p)
         if cfs is not None and c is not None:
             cfs.copy_(c)

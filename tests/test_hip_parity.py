@@ -134,6 +134,7 @@ def test_fused_pass_is_used_and_lean(hip):
     """config-3-like book: the fused kernel is selected and, without `materialize`, no path/exposure tensor is created"""
     sc, _ = cases.make_controller("irs_cva", hip, inject=False)
     sc.materialize = False
+    sc.main_plan = "fused"
     res = sc.run_simulation()
     assert sc._fused is not None and sc.timings.get("fused")
     assert sc.last_state["paths"] is None and sc.last_state["expo"] is None
