@@ -174,6 +174,16 @@ def main():
         total_paths = n_local * world if world == 1 else args.paths * world
         value = total_paths * S * args.steps / dt
         pass_bytes = 8.0 * (2 * T * D + 2 * E + 2) * n_local   # SURVEY.md §8d B_path for the whole pass
+        # HBM bytes per launch of the dominant kernel from the PMC counters (tools/measure_traffic.sh: separate FETCH_SIZE /
+        # WRITE_SIZE passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), measured at 2^20 paths
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            key = "kf_fused" if fused else "k1_paths"
+            if key in pm:
+                traffic = pm[key]["hbm_bytes_per_launch_at_1Mi_paths"] * (n_local / float(1 << 20))
+        except Exception:
+            traffic = None
         # dominant kernel: the fused pass carries the whole pass's algorithmic bytes; unfused K1 only its output tensor
         k1_bytes = pass_bytes if fused else 8.0 * T * D * n_local
         achieved = k1_bytes / (k1_ms * 1e-3) / 1e9
@@ -186,9 +196,9 @@ def main():
                        "paths_per_gpu": n_local, "steps_per_path": S, "state_dim": D, "stored_dates": T,
                        "exposure_dates": E, "presim_paths_per_gpu": args.presim, "parallelism": f"paths x{world}",
                        "execution_plan": best, "plan_probe_ms": plan_ms},
-            "roofline": {"bound": "hbm", "kernel": "kf_fused<2,2> (K1+K2+K4 in one launch)" if fused else "k1_paths<2,2> (Philox+Box-Muller+Cholesky+Euler)",
+            "roofline": {"bound": "hbm", "kernel": "kf_fused<2,2,SIG_VAS_CIR_E> (K1+K2+K4 in one launch)" if fused else "k1_paths<2,2,SIG_VAS_CIR_E> (Philox4x32-10 + Box-Muller + Cholesky + Vasicek/CIR++ Euler)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel_ms": k1_ms, "algorithmic_bytes_per_launch": k1_bytes,
+                         "traffic": traffic, "kernel_ms": k1_ms, "algorithmic_bytes_per_launch": k1_bytes,
                          "whole_pass_algorithmic_GBs": pass_bytes / (dt / args.steps) / 1e9},
             "result": {"cva": cva, "mc_error": err},
             "prepare_s": t_prepare,

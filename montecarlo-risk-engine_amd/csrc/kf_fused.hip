@@ -69,6 +69,17 @@ __device__ __forceinline__ double f_atom(const FAtom& a, const double (&reg)[NRE
     return v;
 }
 
+// coefficients of a STATELESS product are the same for every lane: wave-uniform offset -> scalar loads (s_load through the
+// scalar cache) instead of a dependent per-lane global load with L2 latency on every exposure date
+__device__ __forceinline__ double f_poly_uniform(const double* __restrict__ coeffs, int off_vgpr, int K, double x)
+{
+    const double* __restrict__ c = coeffs + __builtin_amdgcn_readfirstlane(off_vgpr);
+    double v = 0.0, xp = 1.0;
+#pragma unroll 1
+    for (int k = 0; k < K; ++k) { v = fma(ldk(c + k), xp, v); xp *= x; }
+    return v;
+}
+
 __device__ __forceinline__ double f_poly(const double* __restrict__ c, int K, double x)
 {
     double v = 0.0, xp = 1.0;
@@ -119,14 +130,12 @@ __device__ __forceinline__ void kf_on_date(const FusedArgs& a, int t, int64_t i,
     for (int q = 0; q < hd.n_ev; ++q) {
         const FEvent& e = evs[q];
         if (!(e.flags & 2)) inv_num = 1.0 / f_atom<NREG>(e.num, reg);       // flag bit1: same numeraire as the previous event
-        __builtin_amdgcn_sched_barrier(0);   // keep the record reads of each phase close to their use (VGPR live ranges)
         double v = 0.0;
         if (e.kind <= MCX_EV_EXERCISE) {
             double val = 0.0;
 #pragma unroll 1
             for (int j = e.term_begin; j < e.term_end; ++j) {
                 val = fma(terms[j].w, f_atom<NREG>(terms[j].atom, reg), val);
-                __builtin_amdgcn_sched_barrier(0);
             }
             if (e.kind == MCX_EV_CASHFLOW) {
                 v = val * inv_num;
@@ -154,13 +163,14 @@ __device__ __forceinline__ void kf_on_date(const FusedArgs& a, int t, int64_t i,
 #pragma unroll
                 for (int w = 0; w < NSTA; ++w) s = (e.sidx == w) ? est[w] : s;
                 const double x = f_atom<NREG>(e.x, reg);
-                v = (e.coeff_off >= 0 ? f_poly(a.coeffs + e.coeff_off + s * a.n_basis, a.n_basis, x) : 0.0) * inv_num;
+                if (e.coeff_off >= 0)
+                    v = (e.sidx < 0 ? f_poly_uniform(a.coeffs, e.coeff_off + e.init_state * a.n_basis, a.n_basis, x)
+                                    : f_poly(a.coeffs + e.coeff_off + s * a.n_basis, a.n_basis, x)) * inv_num;
             }
 #pragma unroll
             for (int w = 0; w < NNS; ++w) e_ns[w] += (NNS == 1 || e.ns == w) ? v : 0.0;
         }
     }
-    __builtin_amdgcn_sched_barrier(0);
     const int row = ldk(a.date_row + t);
     if (a.expo && row >= 0 && live) {
         for (int w = 0; w < a.n_ns; ++w) {
@@ -183,7 +193,6 @@ __device__ __forceinline__ void kf_on_date(const FusedArgs& a, int t, int64_t i,
         }
         if (mo.has_cva) {
             const double sp = f_atom<NREG>(mo.surv, reg);
-            __builtin_amdgcn_sched_barrier(0);
             const double cs = f_atom<NREG>(mo.cond, reg);
             const double inc = fmax(u, 0.0) * (sp * (1.0 - cs));
 #pragma unroll
