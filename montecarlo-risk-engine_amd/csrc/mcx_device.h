@@ -39,8 +39,8 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     for (int r = 0; r < 10; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;     // v_mad_u64_u32
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c1, k0, 0x96);   // xor3 in one VALU op
+        const uint32_t n2 = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c3, k1, 0x96);
         c1 = (uint32_t)p1;
         c3 = (uint32_t)p0;
         c0 = n0;
@@ -53,8 +53,9 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 
 __device__ __forceinline__ double u53(uint32_t lo, uint32_t hi)
 {
-    const uint64_t x = ((uint64_t)hi << 32) | lo;
-    return ((double)(x >> 11) + 0.5) * 0x1.0p-53;
+    // ((x >> 11) + 0.5) * 2^-53 with x = hi:lo, evaluated as hi*2^-32 + ((lo >> 11)*2^-53 + 2^-54): the inner sum is exact and the
+    // outer fma rounds once, exactly like the oracle's (double)(x >> 11) + 0.5
+    return fma((double)hi, 0x1.0p-32, fma((double)(lo >> 11), 0x1.0p-53, 0x1.0p-54));
 }
 
 // one draw = two uniforms in (0,1) and their Box-Muller pair (include/mcx.h "RNG contract")
@@ -64,7 +65,7 @@ __device__ __forceinline__ void draw_pair(uint64_t seed, uint64_t path, uint32_t
     philox4x32_10((uint32_t)path, (uint32_t)(path >> 32), step, draw, (uint32_t)seed, (uint32_t)(seed >> 32), w0, w1, w2, w3);
     ua = u53(w0, w1);
     const double ub = u53(w2, w3);
-    const double r = sqrt(-2.0 * mcx_log(ua));
+    const double r = mcx_sqrt(-2.0 * mcx_log(ua));
     double s, c;
     mcx_sincos2pi(ub, s, c);
     z0 = r * c;
@@ -111,7 +112,7 @@ __device__ __forceinline__ void step_slot(const mcx_slot& sl, int scheme_rt, int
     }
     case MCX_MODEL_CIRPP: {                                               // cirpp.py:188-198
         const double y = s0;
-        const double sy = sqrt(fmax(y, 0.0));
+        const double sy = mcx_sqrt(fmax(y, 0.0));
         const double yn = y + p[0] * (p[1] - y) * dt + p[2] * sy * sq * zc0;
         s1 = s1 + (y + ldk(aux + 0)) * dt;
         s0 = fmax(yn, 1e-12);

@@ -35,7 +35,13 @@ __device__ __forceinline__ double mcx_log(double x)
     m = lo ? m + m : m;                                       // m in [sqrt(1/2), sqrt(2))
     e -= lo ? 1 : 0;
     const double f = m - 1.0;
-    const double s = f / (2.0 + f);
+    // f / (2 + f) with 2 + f in [1.7, 2.42]: v_rcp_f64 + two Newton steps + one residual correction (no IEEE fix-up paths)
+    const double dd = 2.0 + f;
+    double rr = __builtin_amdgcn_rcp(dd);
+    rr = fma(fma(-dd, rr, 1.0), rr, rr);
+    rr = fma(fma(-dd, rr, 1.0), rr, rr);
+    double s = f * rr;
+    s = fma(fma(-dd, s, f), rr, s);
     const double z = s * s;
     double R = ldk(MCX_LOG_C + 6);
 #pragma unroll
@@ -62,4 +68,21 @@ __device__ __forceinline__ void mcx_sincos2pi(double u, double& s, double& c)
     const double a = swap ? pc : ps, b = swap ? ps : pc;      // sin(theta), cos(theta) up to signs
     s = (q & 2) ? -a : a;
     c = ((q + 1) & 2) ? -b : b;
+}
+
+// sqrt(a) for a >= 0 in the normal range (Box-Muller radius^2, CIR state): v_rsq_f64 seed + Goldschmidt/Newton refinement
+// without the scaling / special-case code of the IEEE-complete library routine.  Correctly rounded in all but ~1e-3 of
+// cases (<= 1 ulp otherwise).
+__device__ __forceinline__ double mcx_sqrt(double a)
+{
+    const double y = __builtin_amdgcn_rsq(a);
+    double g = a * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    double d = fma(-g, g, a);
+    g = fma(d, h, g);
+    d = fma(-g, g, a);
+    g = fma(d, h, g);
+    return a > 0.0 ? g : 0.0;
 }
