@@ -58,14 +58,19 @@ struct FusedArgs {
     int32_t init_state[MCX_FUSED_MAX_STATEFUL];
 };
 
+#define RFL(x) __builtin_amdgcn_readfirstlane(x)
+
 template <int NREG>
 __device__ __forceinline__ double f_atom(const FAtom& a, const double (&reg)[NREG])
 {
+    // the program lives in LDS, so its fields arrive in VGPRs; the CONTROL fields are made wave-uniform SGPRs
+    // (v_readfirstlane) so that selects / branches are scalar instead of exec-masked divergent code
+    const int r = RFL(a.reg), fl = RFL(a.pad);          // pad: bit0 = has exp term, bit1 = has affine term
     double x = 0.0;
 #pragma unroll
-    for (int q = 0; q < NREG; ++q) x = (a.reg == q) ? reg[q] : x;
-    double v = fma(a.d, x, a.a);
-    if (a.b != 0.0) v = fma(a.b, mcx_exp(fma(a.c1, x, a.c0)), v);
+    for (int q = 0; q < NREG; ++q) x = (r == q) ? reg[q] : x;
+    double v = (fl & 2) ? fma(a.d, x, a.a) : 0.0;
+    if (fl & 1) v = fma(a.b, mcx_exp(fma(a.c1, x, a.c0)), v);
     return v;
 }
 
@@ -118,7 +123,9 @@ __device__ __forceinline__ void kf_on_date(const FusedArgs& a, int t, int64_t i,
     const K1Args& k = a.k1;
     const int n_rec = a.n_rec;
     if (STORE && k.paths && live) sim_store_state<NSLOT, SIG>(k, t, i, reg);
-    const ChunkHeader hd = *(const ChunkHeader*)chunk;
+    const ChunkHeader* hdp = (const ChunkHeader*)chunk;
+    ChunkHeader hd;
+    hd.n_ev = RFL(hdp->n_ev); hd.n_mop = RFL(hdp->n_mop); hd.n_terms = RFL(hdp->n_terms); hd.bytes = 0;
     const FEvent* __restrict__ evs = (const FEvent*)(chunk + sizeof(ChunkHeader));
     const FTerm* __restrict__ terms = (const FTerm*)(evs + hd.n_ev);
     const FMetricOp* __restrict__ mops = (const FMetricOp*)(terms + hd.n_terms);
@@ -128,7 +135,10 @@ __device__ __forceinline__ void kf_on_date(const FusedArgs& a, int t, int64_t i,
     double inv_num = 0.0;
 #pragma unroll 1
     for (int q = 0; q < hd.n_ev; ++q) {
-        const FEvent& e = evs[q];
+        const FEvent& ev = evs[q];
+        struct { int kind, flags, term_begin, term_end, coeff_off, ns, sidx, init_state; double strike, sign; const FAtom &num, &x; } e =
+            {RFL(ev.kind), RFL(ev.flags), RFL(ev.term_begin), RFL(ev.term_end), RFL(ev.coeff_off), RFL(ev.ns), RFL(ev.sidx),
+             RFL(ev.init_state), ev.strike, ev.sign, ev.num, ev.x};
         if (!(e.flags & 2)) inv_num = 1.0 / f_atom<NREG>(e.num, reg);       // flag bit1: same numeraire as the previous event
         double v = 0.0;
         if (e.kind <= MCX_EV_EXERCISE) {
@@ -182,7 +192,9 @@ __device__ __forceinline__ void kf_on_date(const FusedArgs& a, int t, int64_t i,
     }
 #pragma unroll 1
     for (int q = 0; q < hd.n_mop; ++q) {
-        const FMetricOp& mo = mops[q];
+        const FMetricOp& mv = mops[q];
+        struct { int ns, rec_profile, has_cva; double threshold; const FAtom &surv, &cond; } mo =
+            {RFL(mv.ns), RFL(mv.rec_profile), RFL(mv.has_cva), mv.threshold, mv.surv, mv.cond};
         double e = e_ns[0];
 #pragma unroll
         for (int w = 1; w < NNS; ++w) e = (mo.ns == w) ? e_ns[w] : e;
@@ -438,7 +450,8 @@ extern "C" int mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_boo
     bool ok = true;
     std::string why;
     auto fatom = [&](const mcx_atom& q, int t_event) {
-        FAtom o; o.pad = 0; o.a = q.a; o.d = q.d; o.b = q.b; o.c0 = q.c0; o.c1 = q.c1; o.reg = -1;
+        FAtom o; o.a = q.a; o.d = q.d; o.b = q.b; o.c0 = q.c0; o.c1 = q.c1; o.reg = -1;
+        o.pad = (q.b != 0.0 ? 1 : 0) | ((q.a != 0.0 || q.d != 0.0) ? 2 : 0);
         if (q.col >= 0) {
             if (q.t_idx != t_event) { ok = false; why = "an event reads the state of another date (unequal swap tenors)"; }
             o.reg = col_reg[q.col];
@@ -517,7 +530,7 @@ extern "C" int mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_boo
             mo.ns = k; mo.m = m; mo.threshold = nd.threshold;
             mo.rec_profile = nd.want_profiles ? rec_prof + 2 * m : -1;
             mo.has_cva = (nd.want_cva && m < nd.n_dates - 1) ? 1 : 0;
-            mo.surv.reg = -1; mo.cond.reg = -1;
+            mo.surv.reg = -1; mo.cond.reg = -1; mo.surv.pad = 0; mo.cond.pad = 0;
             if (mo.has_cva) {
                 const int sa = nd.surv_atoms[m], ca = nd.cond_atoms[m];
                 if (sa < 0 || sa >= book->n_atoms || ca < 0 || ca >= book->n_atoms) { ok = false; why = "CVA atom out of range"; break; }

@@ -93,6 +93,7 @@ class SimulationController:
         self.regression_function = regression_function
         self.requires_higher_order_derivatives = False
         self.use_mfma = use_mfma
+        self.seed_offset = 0         # added to the reference's Philox keys 42 / 43: independent replications of a run
         # the reference accumulates LSM cashflows in a float32 cache (controller.py:312-330); reproduce it for parity
         self.reference_float32_cf_cache = True
         self.allow_fused = True      # fused event/metric program (csrc/kf_fused.hip) when the book is fusable
@@ -295,7 +296,8 @@ class SimulationController:
         be = self.backend
         off, n_local = shard.split(self.num_paths_presim)
         eng = MonteCarloEngine(self.simulation_timeline, self.simulation_scheme, self.model, n_local, self.num_steps,
-                               is_pre_simulation=True, path_offset=off, backend=be, plan=sim_plan, sim=sim)
+                               is_pre_simulation=True, path_offset=off, backend=be, plan=sim_plan, sim=sim,
+                               seed_offset=self.seed_offset)
         if "pre" in self._inject:
             eng.inject_z, eng.inject_u = self._inject["pre"]
         paths = eng.generate_paths_native()
@@ -479,7 +481,7 @@ class SimulationController:
         off, n_local = self._shard.split(self.num_paths_mainsim)
         self._main_engine = MonteCarloEngine(self.simulation_timeline, self.simulation_scheme, self.model, n_local,
                                              self.num_steps, is_pre_simulation=False, path_offset=off, backend=be,
-                                             plan=self.sim_plan, sim=self._sim)
+                                             plan=self.sim_plan, sim=self._sim, seed_offset=self.seed_offset)
         if "main" in self._inject:
             self._main_engine.inject_z, self._main_engine.inject_u = self._inject["main"]
         self._fused = self._build_fused() if (self.allow_fused and self._mc_products) else None

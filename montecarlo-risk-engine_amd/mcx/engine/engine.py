@@ -21,13 +21,13 @@ from ..plan import SimPlan
 class MonteCarloEngine:
     def __init__(self, simulation_timeline, simulation_type: SimulationScheme, model, num_paths: int, num_steps: int,
                  is_pre_simulation: bool = False, *, path_offset: int = 0, backend=None, plan: SimPlan | None = None,
-                 sim=None):
+                 sim=None, seed_offset: int = 0):
         self.simulation_type = simulation_type
         self.model = model
         self.num_paths = int(num_paths)
         self.num_steps = int(num_steps)
         self.simulation_timeline = simulation_timeline
-        self.seed = 42 if is_pre_simulation else 43
+        self.seed = (42 if is_pre_simulation else 43) + int(seed_offset)   # seed_offset: independent replications
         self.path_offset = int(path_offset)
         self.backend = backend if backend is not None else _native.get_backend()
         tl = simulation_timeline.detach().cpu().numpy() if isinstance(simulation_timeline, torch.Tensor) \
