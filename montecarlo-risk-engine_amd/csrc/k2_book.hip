@@ -41,9 +41,10 @@ __device__ __forceinline__ double dev_cash_event(const DevEvent& e, const DevTer
 {
     const double num = dev_atom(e.num, paths, D, ld, i);
     double common = 0.0, own = 0.0;
+    AtomCache ac = {-1, -1, 0.0};
     for (int j = e.term_begin; j < e.term_end; ++j) {
         const DevTerm tm = ldk_struct(&terms[j]);
-        const double v = tm.w * dev_atom(tm.atom, paths, D, ld, i);
+        const double v = tm.w * dev_atom_cached(tm.atom, paths, D, ld, i, ac);
         if (tm.den < 0) common += v;
         else own += v / dev_atom(ldk_struct(&atoms[tm.den]), paths, D, ld, i);
     }

@@ -40,9 +40,10 @@ __device__ __forceinline__ double k3_cash_event(const DevEvent& e, const K3Args&
 {
     const double num = dev_atom(e.num, a.paths, D, a.ld, i);
     double common = 0.0, own = 0.0;
+    AtomCache ac = {-1, -1, 0.0};
     for (int j = e.term_begin; j < e.term_end; ++j) {
         const DevTerm tm = ldk_struct(&a.terms[j]);
-        const double v = tm.w * dev_atom(tm.atom, a.paths, D, a.ld, i);
+        const double v = tm.w * dev_atom_cached(tm.atom, a.paths, D, a.ld, i, ac);
         if (tm.den < 0) common += v;
         else own += v / dev_atom(ldk_struct(&a.atoms[tm.den]), a.paths, D, a.ld, i);
     }

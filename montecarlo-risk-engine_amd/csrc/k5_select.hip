@@ -37,7 +37,20 @@ __global__ __launch_bounds__(MCX_BLOCK) void k5_hist(const DevUnsec u, const dou
         const uint32_t digit = (uint32_t)((k >> shift) & (uint64_t)(nb - 1));
         for (int j = 0; j < n_sel; ++j) {
             const bool match = hi >= 64 || (k >> hi) == (pf.p[j] >> hi);
-            if (match) atomicAdd(&lh[j * nb + digit], 1u);
+            // Exposures of one date share their leading bits, so in the high-order passes most lanes of a wave hit the SAME
+            // bin: aggregate per distinct digit with ballots (one LDS atomic per distinct digit per wave) instead of 64
+            // serialised same-address atomics.
+            unsigned long long todo = __ballot(match);
+            const int lane = threadIdx.x & 63;
+#pragma unroll 1
+            for (int round = 0; round < 2 && todo; ++round) {          // the (at most two) dominant digits of the wave
+                const int leader = __ffsll((long long)todo) - 1;
+                const uint32_t d = (uint32_t)__shfl((int)digit, leader, MCX_WAVE);
+                const unsigned long long same = __ballot(match && digit == d) & todo;
+                if (lane == leader) atomicAdd(&lh[j * nb + d], (uint32_t)__popcll(same));
+                todo &= ~same;
+            }
+            if ((todo >> lane) & 1ull) atomicAdd(&lh[j * nb + digit], 1u);   // scattered remainder: distinct bins, no conflict
         }
     }
     __syncthreads();

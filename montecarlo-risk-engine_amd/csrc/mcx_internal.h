@@ -130,6 +130,25 @@ __device__ __forceinline__ double dev_atom(const DevAtom& a, const double* __res
     return v;
 }
 
+// the terms of one event mostly read the SAME state column of the SAME date (e.g. 64 zero-bond prices of one short rate):
+// keep the last (date, column) -> value in registers instead of re-issuing the global load for every term
+struct AtomCache { int t_idx, col; double x; };
+__device__ __forceinline__ double dev_atom_cached(const DevAtom& a, const double* __restrict__ paths, int64_t D, int64_t ld, int64_t i,
+                                                  AtomCache& c)
+{
+    double x = 0.0;
+    if (a.col >= 0) {
+        if (a.t_idx != c.t_idx || a.col != c.col) {           // wave-uniform test
+            c.x = paths[((int64_t)a.t_idx * D + a.col) * ld + i];
+            c.t_idx = a.t_idx; c.col = a.col;
+        }
+        x = c.x;
+    }
+    double v = fma(a.d, x, a.a);
+    if (a.b != 0.0) v = fma(a.b, mcx_exp(fma(a.c1, x, a.c0)), v);
+    return v;
+}
+
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll
