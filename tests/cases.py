@@ -146,6 +146,16 @@ def mixed_cva():
     return ns, model, RiskMetrics([CVAMetric("cp", 0.4), EPEMetric()], exposure_timeline=np.linspace(0.0, 2.5, 8))
 
 
+def bs_european_exposure():
+    model = BlackScholesModel(0, 100.0, 0.03, 0.25)
+    c = EuropeanOption(Equity(), 1.0, 95.0, OptionType.CALL); c.name = "call"
+    p = EuropeanOption(Equity(), 1.5, 110.0, OptionType.PUT); p.name = "put"
+    ns = [NettingSet(name="opts", products=[c, p], threshold=1.0),
+          NettingSet(name="put_only", products=[EuropeanOption(Equity(), 0.75, 100.0, OptionType.PUT)])]
+    tl = np.array([0.0, 0.25, 0.5, 0.75, 1.0, 1.25, 1.5, 2.0])
+    return ns, model, RiskMetrics([EPEMetric(), PFEMetric(0.9), PVMetric()], exposure_timeline=tl)
+
+
 # name -> (builder, n_pre, n_main, num_steps, scheme, differentiate)
 CASES = {
     "bs_european": (bs_european, 0, 2048, 10, A, False),
@@ -163,6 +173,7 @@ CASES = {
     "netting": (netting, 1024, 1024, 1, A, False),
     "bond_option": (bond_option, 0, 1024, 2, A, False),
     "mixed_cva": (mixed_cva, 512, 512, 2, E, False),
+    "bs_european_exposure": (bs_european_exposure, 0, 1024, 2, A, False),
 }
 
 

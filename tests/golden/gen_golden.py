@@ -438,8 +438,21 @@ def case_mixed_cva():
     return ns, model, RiskMetrics([CVAMetric("cp", 0.4), EPEMetric()], exposure_timeline=tl)
 
 
+def case_bs_european_exposure():
+    """analytic Black-Scholes exposure path (european_option.py:123-145, controller.py:430-437): no regression"""
+    model = BlackScholesModel(0, 100.0, 0.03, 0.25)
+    c = EuropeanOption(Equity(), 1.0, 95.0, OptionType.CALL); c.name = "call"
+    p = EuropeanOption(Equity(), 1.5, 110.0, OptionType.PUT); p.name = "put"
+    ns = [NettingSet(name="opts", products=[c, p], threshold=1.0), NettingSet(name="put_only", products=[EuropeanOption(Equity(), 0.75, 100.0, OptionType.PUT)])]
+    tl = np.array([0.0, 0.25, 0.5, 0.75, 1.0, 1.25, 1.5, 2.0])
+    return ns, model, RiskMetrics([EPEMetric(), PFEMetric(0.9), PVMetric()], exposure_timeline=tl)
+
+
 def main():
     torch.set_num_threads(4)
+    if len(sys.argv) > 1 and sys.argv[1] == "new":
+        run_controller_case("bs_european_exposure", case_bs_european_exposure, 0, 1024, 2, SimulationScheme.ANALYTICAL)
+        return
     gen_steps()
     gen_paths_mc4()
     A, E, Q = SimulationScheme.ANALYTICAL, SimulationScheme.EULER, SimulationScheme.QE
@@ -458,6 +471,7 @@ def main():
     run_controller_case("netting", case_netting, 1024, 1024, 1, A)
     run_controller_case("bond_option", case_bond_option, 0, 1024, 2, A)
     run_controller_case("mixed_cva", case_mixed_cva, 512, 512, 2, E)
+    run_controller_case("bs_european_exposure", case_bs_european_exposure, 0, 1024, 2, A)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,52 @@
+"""Edge cases the reference's tests touch (ragged path counts, a single path -> NaN error (metric.py:33), products past
+maturity -> zero exposure (controller.py:321-322), exposure dates before the first cashflow)."""
+import math
+
+import numpy as np
+import pytest
+
+import cases
+from mcx.controller.controller import SimulationController
+from mcx.metrics.epe_metric import EPEMetric
+from mcx.metrics.pfe_metric import PFEMetric
+from mcx.metrics.pv_metric import PVMetric
+from mcx.metrics.risk_metrics import RiskMetrics
+from mcx.models.vasicek import VasicekModel
+from mcx.products.bond import Bond
+from mcx.products.netting_set import NettingSet
+
+
+def _bond_case(backend, n_main, n_pre, fused=True):
+    model = VasicekModel(0.0, 0.02, 0.04, 0.3, 0.015, asset_id="r")
+    bond = Bond(0.0, 1.0, 1.0, 0.5, True, 0.03, "r")
+    ns = [NettingSet(name="b", products=[bond])]
+    rm = RiskMetrics([EPEMetric(), PFEMetric(0.95), PVMetric()], exposure_timeline=np.array([0.0, 0.5, 1.0, 1.5]))
+    sc = SimulationController(ns, model, rm, n_main, n_pre, 3, cases.E, backend=backend)
+    sc.allow_fused = fused
+    return sc, sc.run_simulation()
+
+
+def test_single_path_gives_nan_error(oracle):
+    sc, res = _bond_case(oracle, 1, 64)
+    pv, err = res.results[0][2][0]
+    assert math.isfinite(pv) and math.isnan(err)
+
+
+def test_exposure_after_maturity_is_zero(oracle):
+    sc, res = _bond_case(oracle, 300, 300)
+    epe = [v for v, _ in res.results[0][0]]
+    assert epe[2] == 0.0 and epe[3] == 0.0           # t = 1.0 (cashflow of that date excluded) and t = 1.5 (past maturity)
+    assert epe[0] > 0.9 and epe[1] > 0.9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 63, 64, 257, 1000, 4097])
+@pytest.mark.parametrize("fused", [True, False])
+def test_ragged_path_counts_gpu_vs_oracle(n, fused, hip, oracle):
+    sg, rg = _bond_case(hip, n, 300, fused)
+    sc, rc = _bond_case(oracle, n, 300, False)
+    for mg, mc in zip(rg.results[0], rc.results[0]):
+        a, b = np.array(mg, dtype=float), np.array(mc, dtype=float)
+        assert np.allclose(a[:, 0], b[:, 0], rtol=1e-9, atol=1e-12, equal_nan=True), (n, a, b)
+        if n > 1:
+            assert np.allclose(a[:, 1], b[:, 1], rtol=1e-6, atol=1e-12, equal_nan=True), (n, a, b)
