@@ -27,6 +27,9 @@ template <int NSLOT, int NZ, bool INJECT, int SIG>
 __global__ __launch_bounds__(MCX_BLOCK) void k1_paths(const K1Args a)
 {
     constexpr int PPL = INJECT ? 1 : MCX_K1_PPL;
+    __shared__ double bm_lds[INJECT ? 2 : MCX_BM_LDS_DOUBLES];
+    const double* tab = nullptr;
+    if (!INJECT) { mcx_bm_load(bm_lds); tab = bm_lds; }
     const int64_t tid = (int64_t)blockIdx.x * MCX_BLOCK + threadIdx.x;
     const int64_t half = (int64_t)gridDim.x * MCX_BLOCK;          // lane handles paths tid + q*half
     if (tid >= a.n) return;
@@ -45,7 +48,7 @@ __global__ __launch_bounds__(MCX_BLOCK) void k1_paths(const K1Args a)
         for (int q = 0; q < PPL; ++q) if (live[q]) sim_store_state<NSLOT, SIG>(a, t, idx[q], reg[q]);
     for (int k = 0; k < a.n_steps; ++k) {
 #pragma unroll
-        for (int q = 0; q < PPL; ++q) sim_substep<NSLOT, NZ, INJECT, SIG>(a, k, a.path_offset + (uint64_t)idx[q], idx[q], reg[q]);
+        for (int q = 0; q < PPL; ++q) sim_substep<NSLOT, NZ, INJECT, SIG>(a, k, a.path_offset + (uint64_t)idx[q], idx[q], reg[q], tab);
         const int st = ldk(&a.steps[k].store_idx);
         if (st >= 0)
 #pragma unroll

@@ -13,6 +13,9 @@
 #include "mcx_device.h"
 
 #include <algorithm>
+#include <type_traits>
+#include <cmath>
+#include <cstdlib>
 
 namespace {
 
@@ -41,8 +44,26 @@ struct FMetricOp {             // one (netting set, metric date) pair, executed 
 
 struct ChunkHeader { int32_t n_ev, n_mop, n_terms, bytes; };
 
+// Straight-line record of a date whose program is the common linear-book shape (one netting set; cashflows that are an
+// affine term + <= 4 exponential terms over a pure-exponential or constant numeraire; stateless polynomial exposures; an
+// optional threshold / EPE-ENE record / CVA increment).  Such a date runs ~130 instructions of branch-light code with every
+// control field in SGPRs instead of ~500 instructions of event interpretation; any other date uses the interpreter.
+struct FastDate {
+    int32_t valid, flags;            // flags: 1 cash, 2 expo, 4 cva, 8 profile, 16 constant numeraire, 32 metric op present
+    int32_t ni_reg, lin_reg, n_exp, x_reg, coeff_off0, coeff_off1, rec_profile, s_reg, c_reg, pad;
+    int32_t t_reg[4];
+    double ni_c0, ni_c1;             // 1/numeraire = exp(ni_c0 + ni_c1 x)   (flag 16: = ni_c0)
+    double k0, k1;                   // cash affine part k0 + k1 * reg[lin_reg]
+    double t_w[4], t_c0[4], t_c1[4];
+    double x_a, x_d;                 // explanatory x = x_a + x_d * reg[x_reg]
+    double thr;
+    double s_b, s_c0, s_c1;          // S(0,t)       = s_b exp(s_c0 + s_c1 reg[s_reg])
+    double c_a, c_b, c_c0, c_c1;     // S(t,t+) cond = c_a + c_b exp(c_c0 + c_c1 reg[c_reg])
+};
+
 struct FusedArgs {
     K1Args k1;
+    const FastDate* __restrict__ fast;        // [n_dates]
     const unsigned char* __restrict__ prog;   // per-date program chunks (header | events | terms | metric ops)
     const int32_t* __restrict__ date_off;     // [n_dates+1] byte offset of each date's chunk (16-byte aligned)
     const int32_t* __restrict__ date_row;     // [n_dates] exposure row of this timeline date or -1
@@ -109,6 +130,80 @@ __device__ __forceinline__ void f_record(double v, bool live, int rec, int n_rec
         acc[0] += s1;
         acc[1] += s2;
     }
+}
+
+template <int NREG>
+__device__ __forceinline__ double f_regsel(int r, const double (&reg)[NREG])      // r is wave-uniform (SGPR)
+{
+    double x = 0.0;
+#pragma unroll
+    for (int q = 0; q < NREG; ++q) x = (r == q) ? reg[q] : x;
+    return x;
+}
+
+// straight-line evaluation of a FastDate (see the struct); returns false when the date must be interpreted
+template <int NSLOT, int SIG, int NNS, bool STORE, bool ALL_FAST>
+__device__ __forceinline__ bool kf_fast_date(const FusedArgs& a, int t, int64_t i, bool live, bool first_tile, double* __restrict__ lds,
+                                             const double (&reg)[2 * NSLOT], double (&cfs)[NNS], double (&cva)[NNS])
+{
+    constexpr int NREG = 2 * NSLOT;
+    if (NNS != 1) return false;
+    if (!ALL_FAST && ldk(&a.fast[t].valid) == 0) return false;
+#ifdef MCX_DBG_NODATE          // timing experiment only: skip the date program
+    return true;
+#endif
+    const FastDate* __restrict__ fp = a.fast + t;                // every field is a scalar load at its point of use
+#define FD(x) ldk(&fp->x)
+    const K1Args& k = a.k1;
+    if (STORE && k.paths && live) sim_store_state<NSLOT, SIG>(k, t, i, reg);
+    const int flags = FD(flags);
+    const double inv = (flags & 16) ? FD(ni_c0) : mcx_exp(fma(FD(ni_c1), f_regsel<NREG>(FD(ni_reg), reg), FD(ni_c0)));
+    if (flags & 1) {
+        double val = fma(FD(k1), f_regsel<NREG>(FD(lin_reg), reg), FD(k0));
+        const int n_exp = FD(n_exp);
+#pragma unroll 1
+        for (int j = 0; j < n_exp; ++j)
+            val = fma(FD(t_w[j]), mcx_exp(fma(FD(t_c1[j]), f_regsel<NREG>(FD(t_reg[j]), reg), FD(t_c0[j]))), val);
+        cfs[0] = fma(val, inv, cfs[0]);
+    }
+    double e = 0.0;
+    if (flags & 2) {
+        const double x = fma(FD(x_d), f_regsel<NREG>(FD(x_reg), reg), FD(x_a));
+        double p = 0.0;
+        const int off0 = FD(coeff_off0), off1 = FD(coeff_off1);
+        if (off0 >= 0) {
+            const double* __restrict__ c = a.coeffs + off0;
+            double xp = 1.0;
+#pragma unroll 1
+            for (int q = 0; q < a.n_basis; ++q) { p = fma(ldk(c + q), xp, p); xp *= x; }
+        }
+        if (off1 >= 0) {
+            const double* __restrict__ c = a.coeffs + off1;
+            double xp = 1.0;
+#pragma unroll 1
+            for (int q = 0; q < a.n_basis; ++q) { p = fma(ldk(c + q), xp, p); xp *= x; }
+        }
+        e = p * inv;
+    }
+    const int row = ldk(a.date_row + t);
+    if (a.expo && row >= 0 && live) a.expo[(int64_t)row * a.ld_out + i] = e;
+    if (flags & 32) {
+        const double u = dev_thr(e, FD(thr));
+        if (flags & 8) {
+            const int rp = FD(rec_profile);
+            f_record(fmax(u, 0.0), live, rp, a.n_rec, first_tile, lds);
+            f_record(fmin(u, 0.0), live, rp + 1, a.n_rec, first_tile, lds);
+        }
+        if (flags & 4) {
+            const double sp = FD(s_b) * mcx_exp(fma(FD(s_c1), f_regsel<NREG>(FD(s_reg), reg), FD(s_c0)));
+            double cs = FD(c_a);
+            const double cb = FD(c_b);
+            if (cb != 0.0) cs = fma(cb, mcx_exp(fma(FD(c_c1), f_regsel<NREG>(FD(c_reg), reg), FD(c_c0))), cs);
+            cva[0] = fma(fmax(u, 0.0), sp * (1.0 - cs), cva[0]);
+        }
+    }
+#undef FD
+    return true;
 }
 
 // The book's events + metric operations of ONE timeline date for one lane.  The date's program chunk sits in the wave's
@@ -236,6 +331,7 @@ __global__ __launch_bounds__(MCX_BLOCK) MCX_KF_ATTR void kf_fused(const FusedArg
     constexpr int NREG = 2 * NSLOT;
     constexpr int NSTA = NST > 0 ? NST : 1;
     constexpr int NPFA = NPF > 0 ? NPF : 1;
+    constexpr bool FAST_ONLY = NPF < 0;          // every date has a FastDate record: no interpreter, no program slots
     extern __shared__ double lds[];
     const K1Args& k = a.k1;
     const int n_rec = a.n_rec;
@@ -243,6 +339,9 @@ __global__ __launch_bounds__(MCX_BLOCK) MCX_KF_ATTR void kf_fused(const FusedArg
     const int rec_area = (9 * n_rec + 1) & ~1;                       // doubles; keeps the program slots 16-byte aligned
     unsigned char* slot = (unsigned char*)(lds + rec_area) + (size_t)wv * a.chunk_cap;       // wave-private program slot
     for (int q = threadIdx.x; q < 9 * n_rec; q += MCX_BLOCK) lds[q] = 0.0;
+    __shared__ double bm_lds[(SIMULATE && !INJECT) ? MCX_BM_LDS_DOUBLES : 2];      // Box-Muller lookup tables
+    const double* tab = nullptr;
+    if (SIMULATE && !INJECT) { mcx_bm_load(bm_lds); tab = bm_lds; }
     __syncthreads();
     const int64_t tiles = (k.n + MCX_BLOCK - 1) / MCX_BLOCK;
     double n_block = 0.0;
@@ -284,24 +383,39 @@ __global__ __launch_bounds__(MCX_BLOCK) MCX_KF_ATTR void kf_fused(const FusedArg
 #pragma unroll
         for (int q = 0; q < NSTA; ++q) est[q] = a.init_state[q];
 
+        auto on_date = [&](int t, auto store) {
+            constexpr bool ST = decltype(store)::value;
+            if (FAST_ONLY) {
+                kf_fast_date<NSLOT, SIG, NNS, ST, true>(a, t, i, live, first_tile, lds, reg, cfs, cva);
+            } else {
+                const bool fast = kf_fast_date<NSLOT, SIG, NNS, ST, false>(a, t, i, live, first_tile, lds, reg, cfs, cva);
+                if (!fast) stage(t);
+                prefetch(t + 1);
+                if (!fast) kf_on_date<NSLOT, SIG, NNS, NSTA, ST>(a, t, i, live, first_tile, lds, slot, reg, cfs, cva, est);
+            }
+        };
         int next_t = 0;                                    // timeline dates are visited in increasing order, each once
-        prefetch(0);
+        if (!FAST_ONLY) prefetch(0);
         if (SIMULATE) {
             for (int t = 0; t < k.n_initial_store; ++t) {
-                stage(t);
-                prefetch(t + 1);
-                kf_on_date<NSLOT, SIG, NNS, NSTA, true>(a, t, i, live, first_tile, lds, slot, reg, cfs, cva, est);
+                on_date(t, std::integral_constant<bool, true>());
                 next_t = t + 1;
             }
             const uint64_t path = k.path_offset + (uint64_t)i;
+            // two nested loops: the inner one is the bare sub-step recursion up to the next timeline date (register
+            // allocation then treats it as the hot loop: the date program's scalars are not kept alive / spilled through it)
+            int step = 0;
 #pragma unroll 1
-            for (int step = 0; step < k.n_steps; ++step) {
-                sim_substep<NSLOT, NZ, INJECT, SIG>(k, step, path, i, reg);
-                const int st = ldk(&k.steps[step].store_idx);
+            while (step < k.n_steps) {
+                int st;
+#pragma unroll 1
+                do {
+                    sim_substep<NSLOT, NZ, INJECT, SIG>(k, step, path, i, reg, tab);
+                    st = ldk(&k.steps[step].store_idx);
+                    ++step;
+                } while (st < 0 && step < k.n_steps);
                 if (st >= 0) {
-                    stage(st);
-                    prefetch(st + 1);
-                    kf_on_date<NSLOT, SIG, NNS, NSTA, true>(a, st, i, live, first_tile, lds, slot, reg, cfs, cva, est);
+                    on_date(st, std::integral_constant<bool, true>());
                     next_t = st + 1;
                 }
             }
@@ -323,9 +437,7 @@ __global__ __launch_bounds__(MCX_BLOCK) MCX_KF_ATTR void kf_fused(const FusedArg
 #pragma unroll
                 for (int q = 0; q < NREG; ++q) reg[q] = nxt[q];
                 if (t + 1 < a.n_dates) load_row(t + 1, nxt);      // next date's state streams in while this date's ops run
-                stage(t);
-                prefetch(t + 1);
-                kf_on_date<NSLOT, SIG, NNS, NSTA, false>(a, t, i, live, first_tile, lds, slot, reg, cfs, cva, est);
+                on_date(t, std::integral_constant<bool, false>());
                 next_t = t + 1;
             }
         }
@@ -392,7 +504,7 @@ void launch_kf(const FusedArgs& a, int grid, size_t lds, int npf, bool inject, b
     const bool one_ns = a.n_ns == 1, no_state = a.n_stateful == 0;
 #define MCX_KF(INJ, NNS, NST, NPF) do { if (simulate) hipLaunchKernelGGL((kf_fused<NSLOT, NZ, INJ, SIG, NNS, NST, NPF, true>), dim3(grid), dim3(MCX_BLOCK), lds, s, a); \
         else if (!INJ) hipLaunchKernelGGL((kf_fused<NSLOT, NZ, false, SIG, NNS, NST, NPF, false>), dim3(grid), dim3(MCX_BLOCK), lds, s, a); } while (0)
-#define MCX_KF_NPF(INJ, NNS, NST) do { if (npf == 1) MCX_KF(INJ, NNS, NST, 1); else if (npf == 2) MCX_KF(INJ, NNS, NST, 2); else MCX_KF(INJ, NNS, NST, 0); } while (0)
+#define MCX_KF_NPF(INJ, NNS, NST) do { if (npf < 0 && NNS == 1 && NST == 0) MCX_KF(INJ, 1, 0, -1); else if (npf == 1) MCX_KF(INJ, NNS, NST, 1); else if (npf == 2) MCX_KF(INJ, NNS, NST, 2); else MCX_KF(INJ, NNS, NST, 0); } while (0)
     if (inject) {
         if (one_ns && no_state) MCX_KF_NPF(true, 1, 0);
         else MCX_KF(true, MCX_FUSED_MAX_NS, MCX_FUSED_MAX_STATEFUL, 0);
@@ -412,6 +524,7 @@ struct mcx_fused {
     const mcx_book* book;
     int n_rec, n_ns, n_dates, n_expo_rows, n_stateful, want_pv;
     unsigned char* d_prog;
+    FastDate* d_fast;
     int32_t* d_date_off;
     int32_t* d_date_row;
     int chunk_cap, npf;
@@ -426,7 +539,7 @@ struct mcx_fused {
 extern "C" void mcx_fused_destroy(mcx_fused* f)
 {
     if (!f) return;
-    hipFree(f->d_prog); hipFree(f->d_date_off); hipFree(f->d_date_row); hipFree(f->d_partials); hipFree(f->d_out);
+    hipFree(f->d_prog); hipFree(f->d_fast); hipFree(f->d_date_off); hipFree(f->d_date_row); hipFree(f->d_partials); hipFree(f->d_out);
     delete f;
 }
 
@@ -544,6 +657,75 @@ extern "C" int mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_boo
     if (n_rec < 1) { delete f; MCX_FAIL(h, MCX_E_NOT_FUSABLE, "not fusable: no reducible metric requested"); }
     if ((size_t)9 * n_rec * sizeof(double) > 48 * 1024) { delete f; MCX_FAIL(h, MCX_E_NOT_FUSABLE, "not fusable: %d records exceed the LDS budget", n_rec); }
 
+    // straight-line records for dates of the linear-book shape (FastDate); such dates need no interpreted chunk
+    std::vector<FastDate> fast(T);
+    for (int t = 0; t < T; ++t) {
+        FastDate fd;
+        memset(&fd, 0, sizeof(fd));
+        fd.ni_reg = fd.lin_reg = fd.x_reg = fd.s_reg = fd.c_reg = -1;
+        fd.coeff_off0 = fd.coeff_off1 = -1; fd.rec_profile = -1;
+        for (int j = 0; j < 4; ++j) fd.t_reg[j] = -1;
+        bool okf = d->n_netting_sets == 1 && getenv("MCX_NO_FAST_DATES") == nullptr;
+        const FAtom* num = nullptr;
+        int n_expo = 0;
+        for (const FEvent& e : by_date[t]) {
+            if (!okf) break;
+            if (e.sidx >= 0 || (e.kind != MCX_EV_CASHFLOW && e.kind != MCX_EV_EXPO_POLY)) { okf = false; break; }
+            if (num && memcmp(num, &e.num, sizeof(FAtom)) != 0) { okf = false; break; }     // one numeraire per date
+            num = &e.num;
+            if (e.kind == MCX_EV_CASHFLOW) {
+                fd.flags |= 1;
+                for (int j = e.term_begin; j < e.term_end && okf; ++j) {
+                    const FTerm& tm = terms_by_date[t][j];
+                    fd.k0 += tm.w * tm.atom.a;
+                    if (tm.atom.d != 0.0) {
+                        if (fd.lin_reg >= 0 && fd.lin_reg != tm.atom.reg) okf = false;
+                        fd.lin_reg = tm.atom.reg; fd.k1 += tm.w * tm.atom.d;
+                    }
+                    if (tm.atom.b != 0.0) {
+                        if (fd.n_exp >= 4) { okf = false; break; }
+                        fd.t_reg[fd.n_exp] = tm.atom.reg; fd.t_w[fd.n_exp] = tm.w * tm.atom.b;
+                        fd.t_c0[fd.n_exp] = tm.atom.c0; fd.t_c1[fd.n_exp] = tm.atom.c1; fd.n_exp++;
+                    }
+                }
+            } else {
+                if (e.x.b != 0.0 || n_expo >= 2) { okf = false; break; }
+                if ((fd.flags & 2) && (fd.x_reg != e.x.reg || fd.x_a != e.x.a || fd.x_d != e.x.d)) { okf = false; break; }
+                fd.flags |= 2; fd.x_reg = e.x.reg; fd.x_a = e.x.a; fd.x_d = e.x.d;
+                const int off = e.coeff_off >= 0 ? e.coeff_off + e.init_state * book->n_basis : -1;
+                (n_expo == 0 ? fd.coeff_off0 : fd.coeff_off1) = off;
+                n_expo++;
+            }
+        }
+        if (okf && num) {
+            if (num->a == 0.0 && num->d == 0.0 && num->b > 0.0) { fd.ni_reg = num->reg; fd.ni_c0 = -num->c0 - log(num->b); fd.ni_c1 = -num->c1; }
+            else if (num->b == 0.0 && num->d == 0.0 && num->a != 0.0) { fd.flags |= 16; fd.ni_c0 = 1.0 / num->a; }
+            else okf = false;
+        }
+        if (okf && mop_by_date[t].size() > 1) okf = false;
+        if (okf && mop_by_date[t].size() == 1) {
+            const FMetricOp& mo = mop_by_date[t][0];
+            fd.flags |= 32; fd.thr = mo.threshold;
+            if (mo.rec_profile >= 0) { fd.flags |= 8; fd.rec_profile = mo.rec_profile; }
+            if (mo.has_cva) {
+                if (mo.surv.a != 0.0 || mo.surv.d != 0.0 || mo.cond.d != 0.0) okf = false;
+                fd.flags |= 4;
+                fd.s_reg = mo.surv.reg; fd.s_b = mo.surv.b; fd.s_c0 = mo.surv.c0; fd.s_c1 = mo.surv.c1;
+                fd.c_reg = mo.cond.reg; fd.c_a = mo.cond.a; fd.c_b = mo.cond.b; fd.c_c0 = mo.cond.c0; fd.c_c1 = mo.cond.c1;
+            }
+        }
+        if (okf && !num && !mop_by_date[t].empty()) { fd.flags |= 16; fd.ni_c0 = 1.0; }      // metric op on an empty date
+        fd.valid = okf ? 1 : 0;
+        fast[t] = fd;
+    }
+    if (getenv("MCX_FUSED_DEBUG")) {
+        int nf = 0;
+        for (int t = 0; t < T; ++t) nf += fast[t].valid;
+        fprintf(stderr, "[mcx] fused program: %d of %d dates straight-line\n", nf, T);
+        for (int t = 0; t < T && t < 4; ++t)
+            fprintf(stderr, "[mcx]  date %d: valid %d flags %d n_ev %zu n_mop %zu n_exp %d\n", t, fast[t].valid, fast[t].flags, by_date[t].size(), mop_by_date[t].size(), fast[t].n_exp);
+    }
+
     // per-date program chunks: header | events | terms | metric ops, 16-byte aligned
     std::vector<unsigned char> prog;
     std::vector<int32_t> date_off(T + 1, 0);
@@ -552,6 +734,7 @@ extern "C" int mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_boo
     for (int t = 0; t < T; ++t) for (const FEvent& e : by_date[t]) if (e.kind == MCX_EV_EXPO_BS) bs_exposure = true;
     for (int t = 0; t < T; ++t) {
         date_off[t] = (int32_t)prog.size();
+        if (fast[t].valid) continue;                   // evaluated from its FastDate record: no interpreted chunk
         ChunkHeader hd;
         hd.n_ev = (int)by_date[t].size(); hd.n_mop = (int)mop_by_date[t].size(); hd.n_terms = (int)terms_by_date[t].size();
         const size_t bytes = sizeof(hd) + sizeof(FEvent) * by_date[t].size() + sizeof(FTerm) * terms_by_date[t].size() +
@@ -570,8 +753,11 @@ extern "C" int mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_boo
     date_off[T] = (int32_t)prog.size();
     if (bs_exposure) { delete f; MCX_FAIL(h, MCX_E_NOT_FUSABLE, "not fusable: analytic Black-Scholes exposures are evaluated by the book kernel (K2)"); }
     // LDS budget: 4 wave slots + the record area must fit comfortably (several blocks per CU)
+    bool all_fast = d->n_netting_sets == 1 && n_stateful == 0;
+    for (int t = 0; t < T; ++t) all_fast = all_fast && fast[t].valid;
     f->npf = max_chunk <= 1024 ? 1 : (max_chunk <= 2048 ? 2 : 0);
     f->chunk_cap = f->npf > 0 ? f->npf * 1024 : ((max_chunk + 255) & ~255);
+    if (all_fast) { f->npf = -1; f->chunk_cap = 0; }      // no interpreted date at all: the straight-line instantiation
     if ((size_t)4 * f->chunk_cap + sizeof(double) * 9 * (size_t)n_rec > 60 * 1024) {
         delete f;
         MCX_FAIL(h, MCX_E_NOT_FUSABLE, "not fusable: a date's event program (%d B) exceeds the per-wave LDS slot budget", max_chunk);
@@ -587,6 +773,7 @@ extern "C" int mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_boo
     };
     prog.resize(prog.size() + 4096, 0);       // slack so the fixed-size prefetch of the last chunk stays in bounds
     MCX_HIP(h, up((void**)&f->d_prog, prog.data(), prog.size()));
+    MCX_HIP(h, up((void**)&f->d_fast, fast.data(), sizeof(FastDate) * fast.size()));
     MCX_HIP(h, up((void**)&f->d_date_off, date_off.data(), sizeof(int32_t) * date_off.size()));
     MCX_HIP(h, up((void**)&f->d_date_row, date_row.data(), sizeof(int32_t) * date_row.size()));
     f->partial_bytes = sizeof(double) * 4 * (size_t)n_rec * 2048;
@@ -611,7 +798,7 @@ static int fused_run_impl(mcx_handle* h, const mcx_fused* f, bool simulate, uint
     FusedArgs a;
     memset(&a, 0, sizeof(a));
     mcx_fill_k1_args(f->sim, seed, path_offset, n_paths, ld > 0 ? ld : n_paths, d_paths, d_inject_z, d_inject_u, &a.k1);
-    a.prog = f->d_prog; a.date_off = f->d_date_off; a.chunk_cap = f->chunk_cap;
+    a.prog = f->d_prog; a.fast = f->d_fast; a.date_off = f->d_date_off; a.chunk_cap = f->chunk_cap;
     a.date_row = f->d_date_row; a.coeffs = f->book->d_coeffs; a.cfs = d_cfs; a.expo = d_expo; a.partials = f->d_partials;
     a.ld_out = ld_out; a.n_dates = f->n_dates; a.n_basis = f->book->n_basis; a.n_ns = f->n_ns; a.n_rec = f->n_rec;
     a.n_expo_rows = f->n_expo_rows; a.n_stateful = f->n_stateful;

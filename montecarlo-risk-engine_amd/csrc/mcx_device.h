@@ -59,17 +59,33 @@ __device__ __forceinline__ double u53(uint32_t lo, uint32_t hi)
 }
 
 // one draw = two uniforms in (0,1) and their Box-Muller pair (include/mcx.h "RNG contract")
-__device__ __forceinline__ void draw_pair(uint64_t seed, uint64_t path, uint32_t step, uint32_t draw, double& ua, double& z0, double& z1)
+// TAB: `tab` is the block's LDS copy of the Box-Muller tables (mcx_bm_load); otherwise polynomial log / sincos
+template <bool TAB = false>
+__device__ __forceinline__ void draw_pair(uint64_t seed, uint64_t path, uint32_t step, uint32_t draw, double& ua, double& z0, double& z1,
+                                          const double* __restrict__ tab = nullptr)
 {
     uint32_t w0, w1, w2, w3;
+#ifdef MCX_DBG_NOPHILOX     // timing experiment only: a cheap (non-random) stand-in for the counter-based generator
+    w0 = (uint32_t)path * 2654435761u + step; w1 = w0 ^ 0x9E3779B9u; w2 = w0 * 3u + draw; w3 = w1 + w2;
+#else
     philox4x32_10((uint32_t)path, (uint32_t)(path >> 32), step, draw, (uint32_t)seed, (uint32_t)(seed >> 32), w0, w1, w2, w3);
+#endif
     ua = u53(w0, w1);
     const double ub = u53(w2, w3);
-    const double r = mcx_sqrt(-2.0 * mcx_log(ua));
-    double s, c;
-    mcx_sincos2pi(ub, s, c);
+#ifdef MCX_DBG_NOBM          // timing experiment only
+    z0 = ua - 0.5; z1 = ub - 0.5;
+#else
+    double s, c, r;
+    if (TAB) {
+        r = mcx_sqrt(-2.0 * mcx_log_tab(ua, tab));
+        mcx_sincos2pi_tab(ub, tab, s, c);
+    } else {
+        r = mcx_sqrt(-2.0 * mcx_log(ua));
+        mcx_sincos2pi(ub, s, c);
+    }
     z0 = r * c;
     z1 = r * s;
+#endif
 }
 
 __device__ __forceinline__ double degree_of_truth(double x, bool fuzzy, double eps)
@@ -214,7 +230,8 @@ __device__ __forceinline__ void step_slots(const K1Args& k, const mcx_step& sp, 
 
 // one sub-step of the whole model for a lane: draws, Cholesky, per-slot maps.  reg[2s], reg[2s+1] = state of slot s.
 template <int NSLOT, int NZ, bool INJECT, int SIG>
-__device__ __forceinline__ void sim_substep(const K1Args& k, int step, uint64_t path, int64_t i, double (&reg)[2 * NSLOT])
+__device__ __forceinline__ void sim_substep(const K1Args& k, int step, uint64_t path, int64_t i, double (&reg)[2 * NSLOT],
+                                            const double* __restrict__ tab)
 {
     const mcx_step sp = ldk_struct(&k.steps[step]);    // wave-uniform -> scalar loads
     double z[NZ], zc[NZ], u = 0.0;
@@ -227,7 +244,7 @@ __device__ __forceinline__ void sim_substep(const K1Args& k, int step, uint64_t 
 #pragma unroll
         for (int q = 0; q < (NZ + 1) / 2; ++q) {
             double z0, z1;
-            draw_pair(k.seed, path, (uint32_t)step, (uint32_t)q, ua, z0, z1);
+            draw_pair<true>(k.seed, path, (uint32_t)step, (uint32_t)q, ua, z0, z1, tab);
             z[2 * q] = z0;
             if (2 * q + 1 < NZ) z[2 * q + 1] = z1;
         }

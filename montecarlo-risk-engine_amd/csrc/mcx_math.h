@@ -86,3 +86,59 @@ __device__ __forceinline__ double mcx_sqrt(double a)
     g = fma(d, h, g);
     return a > 0.0 ? g : 0.0;
 }
+
+// ---- table-driven log / sincos for the Box-Muller transform ----------------------------------------------------------
+// The path kernel is bound by f64 VALU issue (4 clk per wave64 instruction), and ~half of a sub-step was the polynomial
+// log + sincos above (35 + 35 instructions).  A 128-entry table per function (2 x 2 KiB in LDS, one ds_read_b128 per lane —
+// the LDS pipe is otherwise idle in these kernels) shrinks the argument range by 2^7, so a degree-7 log1p and degree-6/7
+// sin/cos corrections are enough: ~16 + ~19 VALU instructions.  Absolute accuracy ~1e-16 (a few ulp of the RESULT away from
+// the table nodes); log(u) keeps full relative accuracy as u -> 1 because the last node is exactly c = 1.
+#include "mcx_tables.h"
+#define MCX_BM_LDS_DOUBLES 512
+
+__device__ const double MCX_LOG1P_C[6] = {-0.5, 1.0 / 3.0, -0.25, 0.2, -1.0 / 6.0, 1.0 / 7.0};
+__device__ const double MCX_TRIG_C[6] = {-1.0 / 6.0, 1.0 / 120.0, -1.0 / 5040.0, -0.5, 1.0 / 24.0, -1.0 / 720.0};
+
+// cooperative copy of both tables into the block's LDS area (MCX_BM_LDS_DOUBLES doubles); includes the barrier
+__device__ __forceinline__ void mcx_bm_load(double* __restrict__ tab)
+{
+    for (int q = threadIdx.x; q < 256; q += blockDim.x) {
+        tab[q] = MCX_LOG_TAB[q];
+        tab[256 + q] = MCX_TRIG_TAB[q];
+    }
+    __syncthreads();
+}
+
+typedef double mcx_d2 __attribute__((ext_vector_type(2)));
+
+// log(x), x a normal double in (0, 1]
+__device__ __forceinline__ double mcx_log_tab(double x, const double* __restrict__ tab)
+{
+    const double m = __builtin_amdgcn_frexp_mant(x);                  // [0.5, 1)
+    const int e = __builtin_amdgcn_frexp_exp(x);
+    const int j = (__double2hiint(m) >> 13) & 127;                     // top 7 mantissa bits
+    const mcx_d2 tc = ((const mcx_d2*)tab)[j];                        // (1/c, log c)
+    const double t = fma(m, tc.x, -1.0);                               // |t| <= 2^-8
+    double q = ldk(MCX_LOG1P_C + 5);
+#pragma unroll
+    for (int k = 4; k >= 0; --k) q = fma(q, t, ldk(MCX_LOG1P_C + k));
+    const double p = fma(t * t, q, t);                                 // log1p(t)
+    const double dk = (double)e;
+    return fma(dk, 6.93147180369123816490e-01, tc.y) + fma(dk, 1.90821492927058770002e-10, p);
+}
+
+// (sin, cos)(2 pi u), u in [0, 1]
+__device__ __forceinline__ void mcx_sincos2pi_tab(double u, const double* __restrict__ tab, double& s, double& c)
+{
+    const double n = rint(u * 128.0);
+    const double d = fma(n, -0.0078125, u) * 6.28318530717958647692;   // |d| <= pi/128
+    const int j = (int)n & 127;
+    const mcx_d2 sc = ((const mcx_d2*)(tab + 256))[j];
+    const double d2 = d * d;
+    const double qs = fma(fma(ldk(MCX_TRIG_C + 2), d2, ldk(MCX_TRIG_C + 1)), d2, ldk(MCX_TRIG_C + 0));
+    const double qc = fma(fma(ldk(MCX_TRIG_C + 5), d2, ldk(MCX_TRIG_C + 4)), d2, ldk(MCX_TRIG_C + 3));
+    const double ps = fma(d * d2, qs, d);                              // sin d
+    const double pc = fma(d2, qc, 1.0);                                // cos d
+    s = fma(sc.x, pc, sc.y * ps);
+    c = fma(-sc.x, ps, sc.y * pc);
+}

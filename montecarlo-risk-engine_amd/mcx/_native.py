@@ -15,7 +15,7 @@ import torch
 from . import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libmcx_hip.so")
+LIB_PATH = os.environ.get("MCX_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "csrc", "libmcx_hip.so")   # override: kernel experiments
 
 _EXPORTS = [
     "mcx_abi_version", "mcx_create", "mcx_destroy", "mcx_last_error", "mcx_device_info",
