@@ -135,10 +135,14 @@ __device__ __forceinline__ void f_record(double v, bool live, int rec, int n_rec
 template <int NREG>
 __device__ __forceinline__ double f_regsel(int r, const double (&reg)[NREG])      // r is wave-uniform (SGPR)
 {
+#ifdef MCX_REGSEL_CHAIN
     double x = 0.0;
 #pragma unroll
     for (int q = 0; q < NREG; ++q) x = (r == q) ? reg[q] : x;
     return x;
+#else
+    return r >= 0 ? reg[r] : 0.0;       // uniform dynamic index -> v_movrels (M0-relative VGPR read), no select chain
+#endif
 }
 
 // straight-line evaluation of a FastDate (see the struct); returns false when the date must be interpreted
@@ -326,7 +330,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // SIMULATE = false: the same event/metric program runs on a paths tensor produced earlier by K1 (`k.paths` is then the
 // INPUT [date][state][path]): one pass over the paths replaces K2 + K4 and writes no exposure matrix unless asked to.
 template <int NSLOT, int NZ, bool INJECT, int SIG, int NNS, int NST, int NPF, bool SIMULATE>
-__global__ __launch_bounds__(MCX_BLOCK) MCX_KF_ATTR void kf_fused(const FusedArgs a)
+__device__ __forceinline__ void kf_body(const FusedArgs& a)
 {
     constexpr int NREG = 2 * NSLOT;
     constexpr int NSTA = NST > 0 ? NST : 1;
@@ -461,6 +465,21 @@ __global__ __launch_bounds__(MCX_BLOCK) MCX_KF_ATTR void kf_fused(const FusedArg
     }
 }
 
+template <int NSLOT, int NZ, bool INJECT, int SIG, int NNS, int NST, int NPF, bool SIMULATE>
+__global__ __launch_bounds__(MCX_BLOCK) MCX_KF_ATTR void kf_fused(const FusedArgs a)
+{
+    kf_body<NSLOT, NZ, INJECT, SIG, NNS, NST, NPF, SIMULATE>(a);
+}
+
+// the straight-line instantiation (every date has a FastDate record).  Forcing it to <= 64 VGPRs (8 waves/SIMD, which would
+// make 2^20 paths = 16 wave-tiles per SIMD exactly two rounds) was measured SLOWER (1.82 vs 1.61 ms): the allocator's own
+// choice (67 VGPRs, 7 waves) stays.
+template <int NSLOT, int NZ, bool INJECT, int SIG, bool SIMULATE>
+__global__ __launch_bounds__(MCX_BLOCK) void kf_fused_lean(const FusedArgs a)
+{
+    kf_body<NSLOT, NZ, INJECT, SIG, 1, 0, -1, SIMULATE>(a);
+}
+
 // merge per-block records (Chan, Golub, LeVeque pairwise update) -> out[r] = (n, mean, 0, M2).
 // One 256-thread block per record: every thread folds a strided subset of the block records (independent loads in
 // flight), the 256 partial triples are then combined through LDS.  (A one-thread serial merge over 2048 dependent loads
@@ -504,7 +523,9 @@ void launch_kf(const FusedArgs& a, int grid, size_t lds, int npf, bool inject, b
     const bool one_ns = a.n_ns == 1, no_state = a.n_stateful == 0;
 #define MCX_KF(INJ, NNS, NST, NPF) do { if (simulate) hipLaunchKernelGGL((kf_fused<NSLOT, NZ, INJ, SIG, NNS, NST, NPF, true>), dim3(grid), dim3(MCX_BLOCK), lds, s, a); \
         else if (!INJ) hipLaunchKernelGGL((kf_fused<NSLOT, NZ, false, SIG, NNS, NST, NPF, false>), dim3(grid), dim3(MCX_BLOCK), lds, s, a); } while (0)
-#define MCX_KF_NPF(INJ, NNS, NST) do { if (npf < 0 && NNS == 1 && NST == 0) MCX_KF(INJ, 1, 0, -1); else if (npf == 1) MCX_KF(INJ, NNS, NST, 1); else if (npf == 2) MCX_KF(INJ, NNS, NST, 2); else MCX_KF(INJ, NNS, NST, 0); } while (0)
+#define MCX_KF_LEAN(INJ) do { if (simulate) hipLaunchKernelGGL((kf_fused_lean<NSLOT, NZ, INJ, SIG, true>), dim3(grid), dim3(MCX_BLOCK), lds, s, a); \
+        else if (!INJ) hipLaunchKernelGGL((kf_fused_lean<NSLOT, NZ, false, SIG, false>), dim3(grid), dim3(MCX_BLOCK), lds, s, a); } while (0)
+#define MCX_KF_NPF(INJ, NNS, NST) do { if (npf < 0 && NNS == 1 && NST == 0) MCX_KF_LEAN(INJ); else if (npf == 1) MCX_KF(INJ, NNS, NST, 1); else if (npf == 2) MCX_KF(INJ, NNS, NST, 2); else MCX_KF(INJ, NNS, NST, 0); } while (0)
     if (inject) {
         if (one_ns && no_state) MCX_KF_NPF(true, 1, 0);
         else MCX_KF(true, MCX_FUSED_MAX_NS, MCX_FUSED_MAX_STATEFUL, 0);
@@ -514,6 +535,7 @@ void launch_kf(const FusedArgs& a, int grid, size_t lds, int npf, bool inject, b
         else MCX_KF(false, MCX_FUSED_MAX_NS, MCX_FUSED_MAX_STATEFUL, 0);
     }
 #undef MCX_KF_NPF
+#undef MCX_KF_LEAN
 #undef MCX_KF
 }
 
