@@ -187,6 +187,16 @@ def main():
         # dominant kernel: the fused pass carries the whole pass's algorithmic bytes; unfused K1 only its output tensor
         k1_bytes = pass_bytes if fused else 8.0 * T * D * n_local
         achieved = k1_bytes / (k1_ms * 1e-3) / 1e9
+        # the kernels are bound by f64 VALU issue, not HBM: companion figure from the SQ counters of
+        # tools/measure_sq.sh (VALU instructions per wave at 2^20 paths) and the live kernel time
+        alu = None
+        try:
+            sq = json.load(open(os.path.join(ROOT, "profiles", "sq_counters.json")))["kf_fused" if fused else "k1_paths"]
+            cycles = sq["valu_insts_per_wave"] * sq["waves"] * (n_local / float(1 << 20)) * 4.0 / sq["n_simd"]
+            alu = {"bound": "f64 VALU issue (4 clk per wave64 instruction)", "valu_insts_per_path_step": sq["valu_insts_per_wave"] * sq["waves"] * 64.0 / ((1 << 20) * S),
+                   "valu_busy_ms_at_2.4GHz": cycles / 2.4e6, "frac": cycles / 2.4e6 / k1_ms}
+        except Exception:
+            alu = None
         out = {
             "metric": "path-steps/sec at 1M paths x 250 steps; PV/CVA rel-error vs CPU ref",
             "value": value, "unit": "path-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -196,10 +206,11 @@ def main():
                        "paths_per_gpu": n_local, "steps_per_path": S, "state_dim": D, "stored_dates": T,
                        "exposure_dates": E, "presim_paths_per_gpu": args.presim, "parallelism": f"paths x{world}",
                        "execution_plan": best, "plan_probe_ms": plan_ms},
-            "roofline": {"bound": "hbm", "kernel": "kf_fused<2,2,SIG_VAS_CIR_E> (K1+K2+K4 in one launch)" if fused else "k1_paths<2,2,SIG_VAS_CIR_E> (Philox4x32-10 + Box-Muller + Cholesky + Vasicek/CIR++ Euler)",
+            "roofline": {"bound": "hbm", "kernel": "kf_fused_lean<2,2,SIG_VAS_CIR_E> (Philox + Box-Muller + SDE + cashflows + LSM exposure + CVA in one launch)" if fused else "k1_paths<2,2,SIG_VAS_CIR_E> (Philox4x32-10 + Box-Muller + Cholesky + Vasicek/CIR++ Euler)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel_ms": k1_ms, "algorithmic_bytes_per_launch": k1_bytes,
                          "whole_pass_algorithmic_GBs": pass_bytes / (dt / args.steps) / 1e9},
+            "alu": alu,
             "result": {"cva": cva, "mc_error": err},
             "prepare_s": t_prepare,
         }

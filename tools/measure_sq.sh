@@ -26,6 +26,18 @@ for k, d in acc.items():
         row[c] = sum(big) / len(big)
     res[k[:90]] = row
 json.dump(res, open(f"{out}/sq_summary.json", "w"), indent=1)
+# compact form read by bench.py (profiles/sq_counters.json)
+compact = {}
+for k, row in res.items():
+    short = "k1_paths" if "k1_paths" in k else "kf_fused"
+    if "SQ_WAVES" in row and "SQ_INSTS_VALU" in row:
+        w = row["SQ_WAVES"]
+        compact[short] = {"kernel": k, "waves": w, "n_simd": 1024, "valu_insts_per_wave": row["SQ_INSTS_VALU"] / w,
+                          "salu_insts_per_wave": row.get("SQ_INSTS_SALU", 0) / w, "smem_insts_per_wave": row.get("SQ_INSTS_SMEM", 0) / w,
+                          "lds_insts_per_wave": row.get("SQ_INSTS_LDS", 0) / w, "wave_cycles_per_wave": row.get("SQ_WAVE_CYCLES", 0) / w,
+                          "wait_inst_any_per_wave": row.get("SQ_WAIT_INST_ANY", 0) / w,
+                          "grbm_gui_active_sum_over_xcds": row.get("GRBM_GUI_ACTIVE", 0)}
+json.dump(compact, open(f"{out}/sq_counters.json", "w"), indent=1)
 for k, row in res.items():
     w = row.get("SQ_WAVES", 0) or 1
     print(k)
