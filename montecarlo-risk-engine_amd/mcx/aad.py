@@ -6,8 +6,15 @@ simulation (controller/controller.py:609-648).  Here the derivative travels FORW
 d PV / d theta_j = mean_j — identical to the reference's pathwise gradient, including the smoothing it switches on
 (`Model.requires_grad`, models/model.py:83-90) and torch's subgradient conventions.
 
-Supported this round (BASELINE configs 2 and 4): PV metrics of European options on an Equity under a single
-Black-Scholes or Heston model.  Sensitivities through the LSM regression (CVA/EPE greeks) are SURVEY §8f rank 1."""
+Tangent kernels exist (BASELINE configs 2 and 4) for PV metrics of European options on an Equity under a single
+Black-Scholes or Heston model.
+
+Every other configuration (`run_with_bumps`): sensitivities through the LSM regression — CVA / EPE / PFE greeks, SURVEY §8f
+rank 1, reference test `tests/pytests/test_cva_large_netting_set_aad_vs_fd.py` — are computed by CENTRAL DIFFERENCES WITH
+COMMON RANDOM NUMBERS: the Philox counters (or the injected draws) are identical in the bumped runs, so the difference
+quotient converges to the same pathwise derivative the reference's tape returns (including the dependence of the regression
+coefficients on the parameters through the pre-simulation), with O(h^2) truncation and no sampling noise.  It costs 2P + 1
+passes of the millisecond-scale hot path instead of one tangent pass; a forward-mode kernel for this path is the next step."""
 from __future__ import annotations
 
 import ctypes as C
@@ -76,3 +83,83 @@ def run_with_tangents(sc):
         grads.append([[tuple(g)] for _ in sc.risk_metrics.metrics])
     sc.timings = dict(total=time.perf_counter() - t0, tangent=True)
     return sc._package(results, grads, [])
+
+
+# ---- central differences with common random numbers ---------------------------------------------------------------------
+def _leaf_models(model):
+    return list(model.models) if hasattr(model, "models") else [model]
+
+
+def _set_param(model, j: int, value: float):
+    """overwrite the j-th entry of `model.get_model_params()` (ModelConfig: concatenation in sub-model order)"""
+    import torch
+    for m in _leaf_models(model):
+        n = len(m.model_params)
+        if j < n:
+            m.model_params[j] = torch.tensor(float(value), dtype=m.model_params[j].dtype)
+            return
+        j -= n
+    raise IndexError("parameter index out of range")
+
+
+def bump_size(theta: float) -> float:
+    return 1e-5 * max(abs(theta), 1e-2)
+
+
+def _clone_controller(sc, model, float32_cache):
+    import copy
+    from .controller.controller import SimulationController
+    clone = SimulationController(copy.deepcopy(sc.netting_sets), model, copy.deepcopy(sc.risk_metrics), sc.num_paths_mainsim,
+                                 sc.num_paths_presim, sc.num_steps, sc.simulation_scheme, differentiate=False,
+                                 regression_function=sc.regression_function, backend=sc.backend, use_mfma=sc.use_mfma)
+    for attr in ("seed_offset", "allow_fused", "main_plan", "materialize", "_inject"):
+        setattr(clone, attr, getattr(sc, attr))
+    clone.reference_float32_cf_cache = float32_cache
+    return clone
+
+
+def run_with_bumps(sc):
+    import copy
+    if sc.requires_higher_order_derivatives:
+        raise NotImplementedError("second-order derivatives are not implemented")
+    t0 = time.perf_counter()
+    smoothing = getattr(sc.model, "perform_smoothing", False)      # the reference differentiates the smoothed payoffs
+    base = _clone_controller(sc, sc.model, sc.reference_float32_cf_cache)
+    res0 = base.run_simulation()
+    sc.sim_plan, sc.last_state = base.sim_plan, base.last_state
+    theta = [float(p.detach()) for p in sc.model.get_model_params()]
+    P = len(theta)
+    vals = []                       # [param][sign] -> nested results
+    for j in range(P):
+        h = bump_size(theta[j])
+        pair = []
+        for sgn in (+1.0, -1.0):
+            m = copy.deepcopy(sc.model)
+            m.perform_smoothing = smoothing
+            for leaf in _leaf_models(m):
+                leaf.perform_smoothing = smoothing
+            _set_param(m, j, theta[j] + sgn * h)
+            # the float32 cashflow cache of the reference's LSM is a rounding artefact: differencing through it would only add
+            # noise of size eps_f32 / h, so the bumped pair runs with the float64 cache
+            pair.append(_clone_controller(sc, m, False).run_simulation().results)
+        vals.append((pair, h))
+    grads = []
+    for ns_i, per_metric in enumerate(res0.results):
+        gm = []
+        for m_i, evals in enumerate(per_metric):
+            ge = []
+            for e_i in range(len(evals)):
+                ge.append(tuple((float(vals[j][0][0][ns_i][m_i][e_i][0]) - float(vals[j][0][1][ns_i][m_i][e_i][0])) / (2.0 * vals[j][1])
+                                for j in range(P)))
+            gm.append(ge)
+        grads.append(gm)
+    sc.timings = dict(total=time.perf_counter() - t0, tangent=False, bumped_passes=2 * P)
+    return sc._package([[[tuple(v) for v in evals] for evals in per_metric] for per_metric in res0.results], grads, [])
+
+
+def tangent_kernels_apply(sc) -> bool:
+    try:
+        _check_supported(sc)
+        return True
+    except NotImplementedError:
+        return False

@@ -566,8 +566,8 @@ class SimulationController:
 
     def run_simulation(self) -> SimulationResults:
         if self.differentiate:
-            from ..aad import run_with_tangents
-            return run_with_tangents(self)
+            from ..aad import run_with_bumps, run_with_tangents, tangent_kernels_apply
+            return run_with_tangents(self) if tangent_kernels_apply(self) else run_with_bumps(self)
         t0 = time.perf_counter()
         be = self.backend
         self.prepare()

@@ -174,7 +174,11 @@ CASES = {
     "bond_option": (bond_option, 0, 1024, 2, A, False),
     "mixed_cva": (mixed_cva, 512, 512, 2, E, False),
     "bs_european_exposure": (bs_european_exposure, 0, 1024, 2, A, False),
+    # sensitivities through the LSM regression; the fixtures hold only the reference gradients, draws = the base case's
+    "irs_cva_aad": (irs_cva, 1024, 1024, 2, E, True),
+    "mixed_cva_aad": (mixed_cva, 512, 512, 2, E, True),
 }
+DRAWS_FROM = {"irs_cva_aad": "irs_cva", "mixed_cva_aad": "mixed_cva"}
 
 
 def load_golden(name):
@@ -188,12 +192,13 @@ def make_controller(name, backend, inject=True, fused=True):
     sc.materialize = True
     sc.allow_fused = fused
     g = load_golden(name)
+    gd = load_golden(DRAWS_FROM.get(name, name))
     if inject:
         def prep(key_z, key_u):
-            z = backend.from_numpy(np.ascontiguousarray(np.transpose(g[key_z], (0, 2, 1))))      # [S][n_z][N]
-            u = backend.from_numpy(np.ascontiguousarray(g[key_u][:, :, 0])) if key_u in g.files else None
+            z = backend.from_numpy(np.ascontiguousarray(np.transpose(gd[key_z], (0, 2, 1))))      # [S][n_z][N]
+            u = backend.from_numpy(np.ascontiguousarray(gd[key_u][:, :, 0])) if key_u in gd.files else None
             return z, u
         sc._inject["main"] = prep("z_main", "u_main")
-        if "z_pre" in g.files:
+        if "z_pre" in gd.files:
             sc._inject["pre"] = prep("z_pre", "u_pre")
     return sc, g

@@ -451,7 +451,8 @@ def case_bs_european_exposure():
 def main():
     torch.set_num_threads(4)
     if len(sys.argv) > 1 and sys.argv[1] == "new":
-        run_controller_case("bs_european_exposure", case_bs_european_exposure, 0, 1024, 2, SimulationScheme.ANALYTICAL)
+        run_controller_case("irs_cva_aad", case_irs_cva, 1024, 1024, 2, SimulationScheme.EULER, differentiate=True)
+        run_controller_case("mixed_cva_aad", case_mixed_cva, 512, 512, 2, SimulationScheme.EULER, differentiate=True)
         return
     gen_steps()
     gen_paths_mc4()
@@ -472,6 +473,9 @@ def main():
     run_controller_case("bond_option", case_bond_option, 0, 1024, 2, A)
     run_controller_case("mixed_cva", case_mixed_cva, 512, 512, 2, E)
     run_controller_case("bs_european_exposure", case_bs_european_exposure, 0, 1024, 2, A)
+    # sensitivities through the LSM regression (controller.py:609-627)
+    run_controller_case("irs_cva_aad", case_irs_cva, 1024, 1024, 2, E, differentiate=True)
+    run_controller_case("mixed_cva_aad", case_mixed_cva, 512, 512, 2, E, differentiate=True)
 
 
 if __name__ == "__main__":

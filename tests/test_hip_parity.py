@@ -150,7 +150,8 @@ def test_unfusable_books_fall_back(hip):
     assert sc._fused is None
 
 
-AAD = [n for n, c in cases.CASES.items() if c[5]]
+AAD = [n for n, c in cases.CASES.items() if c[5] and n not in cases.DRAWS_FROM]         # tangent-kernel cases
+LSM_AAD = [n for n in cases.DRAWS_FROM]                                               # sensitivities through the regression
 
 
 @pytest.mark.parametrize("name", AAD)
@@ -189,3 +190,11 @@ def test_bs_delta_anchor(hip):
     assert abs(pv - 31.96482) < 4 * err
     assert abs(d["spot"] - delta) < 2e-3, (d["spot"], delta)
     assert abs(d["volatility"] - vega) / vega < 2e-2, (d["volatility"], vega)
+
+
+@pytest.mark.parametrize("name", LSM_AAD)
+def test_lsm_sensitivities_against_reference_autograd(name, hip):
+    from test_oracle_golden import check_lsm_sensitivities
+    sc, g = cases.make_controller(name, hip)
+    res = sc.run_simulation()
+    check_lsm_sensitivities(sc, g, res)

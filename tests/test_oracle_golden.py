@@ -61,7 +61,8 @@ def test_case_against_reference(name, oracle):
     assert list(res.netting_set_names) == list(g["netting_set_names"])
 
 
-AAD = [n for n, c in cases.CASES.items() if c[5]]
+AAD = [n for n, c in cases.CASES.items() if c[5] and n not in cases.DRAWS_FROM]         # tangent-kernel cases
+LSM_AAD = [n for n in cases.DRAWS_FROM]                                               # sensitivities through the regression
 
 
 @pytest.mark.parametrize("name", AAD)
@@ -77,3 +78,30 @@ def test_tangents_against_reference_autograd(name, oracle):
     assert list(res.model_param_names) == list(g["param_names"])
     d = res.get_derivatives(0, "pv", evaluation_idx=0)
     assert set(d) == set(g["param_names"])
+
+
+def check_lsm_sensitivities(sc, g, res):
+    """CVA / EPE sensitivities through the LSM regression (reference: torch.autograd through lstsq, controller.py:609-627) vs the
+    common-random-number central differences of mcx.aad.run_with_bumps on the reference's recorded draws"""
+    assert list(res.model_param_names) == list(g["param_names"])
+    for ns_i in range(len(res.results)):
+        for m_i in range(len(res.results[ns_i])):
+            ref_v = g[f"result_{ns_i}_{m_i}"]
+            ours_v = np.array(res.results[ns_i][m_i], dtype=np.float64)
+            assert np.allclose(ours_v[:, 0], ref_v[:, 0], rtol=1e-8, atol=1e-10)
+            ref = g[f"grad_{ns_i}_{m_i}"]
+            ours = np.array(res.derivatives[ns_i][m_i], dtype=np.float64)
+            assert ours.shape == ref.shape
+            unused = np.isnan(ref)                   # parameters the reference's tape never touches (deterministic credit)
+            assert np.all(np.abs(ours[unused]) < 1e-12)
+            scale = np.max(np.abs(ref[~unused].reshape(ref.shape[0], -1)), axis=1, keepdims=True) if (~unused).any() else 1.0
+            err = np.abs(np.where(unused, 0.0, ours - ref))
+            tol = 2e-6 * np.maximum(np.abs(np.where(unused, 0.0, ref)), 1e-3 * np.broadcast_to(scale, ref.shape)) + 1e-10
+            assert np.all(err <= tol), (ns_i, m_i, ours, ref)
+
+
+@pytest.mark.parametrize("name", LSM_AAD)
+def test_lsm_sensitivities_against_reference_autograd(name, oracle):
+    sc, g = cases.make_controller(name, oracle)
+    res = sc.run_simulation()
+    check_lsm_sensitivities(sc, g, res)
