@@ -40,16 +40,23 @@ __device__ __forceinline__ double dev_cash_event(const DevEvent& e, const DevTer
                                                  int64_t D, int64_t ld, int64_t i, int& s)
 {
     const double num = dev_atom(e.num, paths, D, ld, i);
-    double common = 0.0, own = 0.0;
+    double common = 0.0, own = 0.0, glog = 0.0;
+    const bool basket = e.kind == MCX_EV_OPTION && e.aux[0] != 0.0;       // geometric aggregate needed (basket_option.py:56-82)
     AtomCache ac = {-1, -1, 0.0};
     for (int j = e.term_begin; j < e.term_end; ++j) {
         const DevTerm tm = ldk_struct(&terms[j]);
-        const double v = tm.w * dev_atom_cached(tm.atom, paths, D, ld, i, ac);
+        const double av = dev_atom_cached(tm.atom, paths, D, ld, i, ac);
+        const double v = tm.w * av;
+        if (basket) glog = fma(tm.w, mcx_log(av + 1e-10), glog);
         if (tm.den < 0) common += v;
         else own += v / dev_atom(ldk_struct(&atoms[tm.den]), paths, D, ld, i);
     }
     if (e.kind == MCX_EV_CASHFLOW) return common / num + own;
     const double imm = fmax(e.sign * (common - e.strike), 0.0);
+    if (basket) {
+        const double geo = fmax(e.sign * (mcx_exp(glog) - e.strike), 0.0);
+        return (e.aux[0] == 1.0 ? geo : imm - geo + e.aux[1]) / num;
+    }
     if (e.kind == MCX_EV_OPTION) return imm / num;
     double cont = 0.0;                                        // MCX_EV_EXERCISE (bermudan_option.py:93-131)
     if (e.coeff_off >= 0) cont = dev_poly(coeffs + e.coeff_off + s * K, K, dev_atom(e.x, paths, D, ld, i));

@@ -39,16 +39,23 @@ __device__ __forceinline__ double k3_poly(const double* __restrict__ c, int K, d
 __device__ __forceinline__ double k3_cash_event(const DevEvent& e, const K3Args& a, int64_t D, int64_t i, int& s)
 {
     const double num = dev_atom(e.num, a.paths, D, a.ld, i);
-    double common = 0.0, own = 0.0;
+    double common = 0.0, own = 0.0, glog = 0.0;
+    const bool basket = e.kind == MCX_EV_OPTION && e.aux[0] != 0.0;       // geometric aggregate needed (basket_option.py:56-82)
     AtomCache ac = {-1, -1, 0.0};
     for (int j = e.term_begin; j < e.term_end; ++j) {
         const DevTerm tm = ldk_struct(&a.terms[j]);
-        const double v = tm.w * dev_atom_cached(tm.atom, a.paths, D, a.ld, i, ac);
+        const double av = dev_atom_cached(tm.atom, a.paths, D, a.ld, i, ac);
+        const double v = tm.w * av;
+        if (basket) glog = fma(tm.w, mcx_log(av + 1e-10), glog);
         if (tm.den < 0) common += v;
         else own += v / dev_atom(ldk_struct(&a.atoms[tm.den]), a.paths, D, a.ld, i);
     }
     if (e.kind == MCX_EV_CASHFLOW) return common / num + own;
     const double imm = fmax(e.sign * (common - e.strike), 0.0);
+    if (basket) {
+        const double geo = fmax(e.sign * (mcx_exp(glog) - e.strike), 0.0);
+        return (e.aux[0] == 1.0 ? geo : imm - geo + e.aux[1]) / num;
+    }
     if (e.kind == MCX_EV_OPTION) return imm / num;
     double cont = 0.0;
     if (e.coeff_off >= 0) cont = k3_poly(a.coeffs + e.coeff_off + s * a.n_basis, a.n_basis, dev_atom(e.x, a.paths, D, a.ld, i));

@@ -241,10 +241,13 @@ __device__ __forceinline__ void kf_on_date(const FusedArgs& a, int t, int64_t i,
         if (!(e.flags & 2)) inv_num = 1.0 / f_atom<NREG>(e.num, reg);       // flag bit1: same numeraire as the previous event
         double v = 0.0;
         if (e.kind <= MCX_EV_EXERCISE) {
-            double val = 0.0;
+            double val = 0.0, glog = 0.0;
+            const int basket = e.kind == MCX_EV_OPTION ? RFL((int)ev.aux[0]) : 0;      // basket aggregation mode (basket_option.py)
 #pragma unroll 1
             for (int j = e.term_begin; j < e.term_end; ++j) {
-                val = fma(terms[j].w, f_atom<NREG>(terms[j].atom, reg), val);
+                const double av = f_atom<NREG>(terms[j].atom, reg);
+                val = fma(terms[j].w, av, val);
+                if (basket) glog = fma(terms[j].w, mcx_log(av + 1e-10), glog);
             }
             if (e.kind == MCX_EV_CASHFLOW) {
                 v = val * inv_num;
@@ -252,6 +255,10 @@ __device__ __forceinline__ void kf_on_date(const FusedArgs& a, int t, int64_t i,
                 const double imm = fmax(e.sign * (val - e.strike), 0.0);
                 if (e.kind == MCX_EV_OPTION) {
                     v = imm * inv_num;
+                    if (basket) {
+                        const double geo = fmax(e.sign * (mcx_exp(glog) - e.strike), 0.0);
+                        v = (basket == 1 ? geo : imm - geo + ev.aux[1]) * inv_num;
+                    }
                 } else {
                     int s = 0;
 #pragma unroll

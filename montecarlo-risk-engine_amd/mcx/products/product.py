@@ -29,6 +29,7 @@ class ProductFamily(Enum):
     GENERIC = "generic"
     VANILLA_TERMINAL_OPTION = "vanilla_terminal_option"
     BERMUDAN_EXERCISE = "bermudan_exercise"
+    BASKET_TERMINAL_PAYOFF = "basket_terminal_payoff"
 
 
 @dataclass
@@ -41,6 +42,7 @@ class CashEvent:
     sign: float = 1.0
     x_asset: str | None = None      # EXERCISE: explanatory SPOT asset
     reg_idx: int | None = None      # EXERCISE: index into product.regression_coeffs (None: continuation 0)
+    aux: tuple = (0.0, 0.0, 0.0, 0.0)   # OPTION: basket aggregation mode + control-variate constant (include/mcx.h)
 
 
 class Product:

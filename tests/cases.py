@@ -15,10 +15,12 @@ from mcx.metrics.pfe_metric import PFEMetric
 from mcx.metrics.pv_metric import PVMetric
 from mcx.metrics.risk_metrics import RiskMetrics
 from mcx.models.black_scholes import BlackScholesModel
+from mcx.models.black_scholes_multi import BlackScholesMulti
 from mcx.models.cirpp import CIRPPModel
 from mcx.models.heston import HestonModel
 from mcx.models.model_config import ModelConfig
 from mcx.models.vasicek import VasicekModel
+from mcx.products.basket_option import BasketOption, BasketOptionType
 from mcx.products.bermudan_option import AmericanOption, BermudanOption
 from mcx.products.bond import Bond
 from mcx.products.equity import Equity
@@ -146,6 +148,26 @@ def mixed_cva():
     return ns, model, RiskMetrics([CVAMetric("cp", 0.4), EPEMetric()], exposure_timeline=np.linspace(0.0, 2.5, 8))
 
 
+def _baskets(ids, cv):
+    b = BasketOption(1.0, ids, [0.4, 0.3, 0.2, 0.1], 100, OptionType.CALL, BasketOptionType.ARITHMETIC, cv); b.name = "basket_arithmetic"
+    g = BasketOption(1.0, ids, [0.4, 0.3, 0.2, 0.1], 95, OptionType.PUT, BasketOptionType.GEOMETRIC); g.name = "basket_geometric"
+    return [NettingSet(name=b.get_name(), products=[b]), NettingSet(name=g.get_name(), products=[g])]
+
+
+def basket_model_config():
+    ids = ["asset1", "asset2", "asset3", "asset4"]
+    models = [BlackScholesModel(0.0, 100.0 + 5 * k, 0.02, 0.4 - 0.05 * k, asset_id=ids[k]) for k in range(4)]
+    model = ModelConfig(models=models, inter_asset_correlation_matrix=np.array([[0.5], [0.3], [0.1], [0.5], [0.2], [0.4]]))
+    return _baskets(ids, False), model, RiskMetrics([PVMetric()])
+
+
+def basket_multi():
+    ids = ["asset1", "asset2", "asset3", "asset4"]
+    corr = np.array([[1.0, 0.5, 0.3, 0.1], [0.5, 1.0, 0.5, 0.2], [0.3, 0.5, 1.0, 0.4], [0.1, 0.2, 0.4, 1.0]])
+    model = BlackScholesMulti(0.0, 0.02, ids, [100.0, 105.0, 110.0, 115.0], [0.4, 0.35, 0.3, 0.25], corr)
+    return _baskets(ids, True), model, RiskMetrics([PVMetric()])
+
+
 def bs_european_exposure():
     model = BlackScholesModel(0, 100.0, 0.03, 0.25)
     c = EuropeanOption(Equity(), 1.0, 95.0, OptionType.CALL); c.name = "call"
@@ -174,6 +196,10 @@ CASES = {
     "bond_option": (bond_option, 0, 1024, 2, A, False),
     "mixed_cva": (mixed_cva, 512, 512, 2, E, False),
     "bs_european_exposure": (bs_european_exposure, 0, 1024, 2, A, False),
+    "basket_model_config": (basket_model_config, 0, 1024, 2, A, False),
+    "basket_model_config_euler": (basket_model_config, 0, 1024, 4, E, False),
+    "basket_multi": (basket_multi, 0, 1024, 2, A, False),
+    "basket_multi_euler": (basket_multi, 0, 1024, 3, E, False),
     # sensitivities through the LSM regression; the fixtures hold only the reference gradients, draws = the base case's
     "irs_cva_aad": (irs_cva, 1024, 1024, 2, E, True),
     "mixed_cva_aad": (mixed_cva, 512, 512, 2, E, True),

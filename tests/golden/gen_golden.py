@@ -33,10 +33,12 @@ from metrics.pfe_metric import PFEMetric
 from metrics.pv_metric import PVMetric
 from metrics.risk_metrics import RiskMetrics
 from models.black_scholes import BlackScholesModel
+from models.black_scholes_multi import BlackScholesMulti
 from models.cirpp import CIRPPModel
 from models.heston import HestonModel
 from models.model_config import ModelConfig
 from models.vasicek import VasicekModel
+from products.basket_option import BasketOption, BasketOptionType
 from products.bermudan_option import AmericanOption, BermudanOption
 from products.bond import Bond
 from products.equity import Equity
@@ -438,6 +440,28 @@ def case_mixed_cva():
     return ns, model, RiskMetrics([CVAMetric("cp", 0.4), EPEMetric()], exposure_timeline=tl)
 
 
+def _baskets(ids, cv):
+    b = BasketOption(1.0, ids, [0.4, 0.3, 0.2, 0.1], 100, OptionType.CALL, BasketOptionType.ARITHMETIC, cv); b.name = "basket_arithmetic"
+    g = BasketOption(1.0, ids, [0.4, 0.3, 0.2, 0.1], 95, OptionType.PUT, BasketOptionType.GEOMETRIC); g.name = "basket_geometric"
+    return [NettingSet(name=b.get_name(), products=[b]), NettingSet(name=g.get_name(), products=[g])]
+
+
+def case_basket_model_config():
+    """4 correlated Black-Scholes models in a ModelConfig + arithmetic / geometric baskets (tests/pytests/test_model_config.py:18-71)"""
+    ids = ["asset1", "asset2", "asset3", "asset4"]
+    models = [BlackScholesModel(0.0, 100.0 + 5 * k, 0.02, 0.4 - 0.05 * k, asset_id=ids[k]) for k in range(4)]
+    model = ModelConfig(models=models, inter_asset_correlation_matrix=np.array([[0.5], [0.3], [0.1], [0.5], [0.2], [0.4]]))
+    return _baskets(ids, False), model, RiskMetrics([PVMetric()])
+
+
+def case_basket_multi():
+    """BlackScholesMulti + arithmetic basket with the geometric control variate (tests/pytests/test_pv_basket_option.py:16-69)"""
+    ids = ["asset1", "asset2", "asset3", "asset4"]
+    corr = np.array([[1.0, 0.5, 0.3, 0.1], [0.5, 1.0, 0.5, 0.2], [0.3, 0.5, 1.0, 0.4], [0.1, 0.2, 0.4, 1.0]])
+    model = BlackScholesMulti(0.0, 0.02, ids, [100.0, 105.0, 110.0, 115.0], [0.4, 0.35, 0.3, 0.25], corr)
+    return _baskets(ids, True), model, RiskMetrics([PVMetric()])
+
+
 def case_bs_european_exposure():
     """analytic Black-Scholes exposure path (european_option.py:123-145, controller.py:430-437): no regression"""
     model = BlackScholesModel(0, 100.0, 0.03, 0.25)
@@ -451,8 +475,10 @@ def case_bs_european_exposure():
 def main():
     torch.set_num_threads(4)
     if len(sys.argv) > 1 and sys.argv[1] == "new":
-        run_controller_case("irs_cva_aad", case_irs_cva, 1024, 1024, 2, SimulationScheme.EULER, differentiate=True)
-        run_controller_case("mixed_cva_aad", case_mixed_cva, 512, 512, 2, SimulationScheme.EULER, differentiate=True)
+        run_controller_case("basket_model_config", case_basket_model_config, 0, 1024, 2, SimulationScheme.ANALYTICAL)
+        run_controller_case("basket_model_config_euler", case_basket_model_config, 0, 1024, 4, SimulationScheme.EULER)
+        run_controller_case("basket_multi", case_basket_multi, 0, 1024, 2, SimulationScheme.ANALYTICAL)
+        run_controller_case("basket_multi_euler", case_basket_multi, 0, 1024, 3, SimulationScheme.EULER)
         return
     gen_steps()
     gen_paths_mc4()
@@ -476,6 +502,11 @@ def main():
     # sensitivities through the LSM regression (controller.py:609-627)
     run_controller_case("irs_cva_aad", case_irs_cva, 1024, 1024, 2, E, differentiate=True)
     run_controller_case("mixed_cva_aad", case_mixed_cva, 512, 512, 2, E, differentiate=True)
+    # baskets: ModelConfig of n Black-Scholes models, BlackScholesMulti
+    run_controller_case("basket_model_config", case_basket_model_config, 0, 1024, 2, A)
+    run_controller_case("basket_model_config_euler", case_basket_model_config, 0, 1024, 4, E)
+    run_controller_case("basket_multi", case_basket_multi, 0, 1024, 2, A)
+    run_controller_case("basket_multi_euler", case_basket_multi, 0, 1024, 3, E)
 
 
 if __name__ == "__main__":

@@ -198,3 +198,35 @@ def test_lsm_sensitivities_against_reference_autograd(name, hip):
     sc, g = cases.make_controller(name, hip)
     res = sc.run_simulation()
     check_lsm_sensitivities(sc, g, res)
+
+
+def test_basket_anchors_of_the_reference_tests(hip):
+    """tests/pytests/test_model_config.py:18-71 and test_pv_basket_option.py:16-69 at their own sizes: arithmetic basket 12.60,
+    geometric basket = its closed form 10.9551100513373 (ModelConfig of 4 BS models, 1 M paths; BlackScholesMulti with the
+    geometric control variate)"""
+    from mcx.models.black_scholes_multi import BlackScholesMulti
+    from mcx.products.basket_option import BasketOption, BasketOptionType
+    ids = ["asset1", "asset2", "asset3", "asset4"]
+
+    def book(cv):
+        b = BasketOption(1.0, ids, [0.25] * 4, 100, cases.OptionType.CALL, BasketOptionType.ARITHMETIC, cv); b.name = "basket_arithmetic"
+        g = BasketOption(1.0, ids, [0.25] * 4, 100, cases.OptionType.CALL, BasketOptionType.GEOMETRIC); g.name = "basket_geometric"
+        return b, g, [cases.NettingSet(name=b.get_name(), products=[b]), cases.NettingSet(name=g.get_name(), products=[g])]
+
+    for scheme, steps in ((cases.A, 1), (cases.E, 50)):
+        models = [cases.BlackScholesModel(0.0, 100.0, 0.0, 0.4, asset_id=a) for a in ids]
+        model = cases.ModelConfig(models=models, inter_asset_correlation_matrix=np.array([[0.5]] * 6))
+        b, g, ns = book(False)
+        sc = cases.SimulationController(ns, model, cases.RiskMetrics([cases.PVMetric()]), 1000000, 0, steps, scheme, backend=hip)
+        res = sc.run_simulation()
+        (pa, ea), (pg, eg) = res.results[0][0][0], res.results[1][0][0]
+        assert abs(pa - 12.60) < 0.02 + 3 * ea and abs(pg - 10.9551100513373) < 3.5 * eg + (0.02 if scheme == cases.E else 0.0), (scheme, pa, pg)
+        assert abs(res.get_results(b.get_name(), "pv", evaluation_idx=0) - pa) == 0.0
+    corr = np.full((4, 4), 0.5); np.fill_diagonal(corr, 1.0)
+    model = BlackScholesMulti(0.0, 0.0, ids, [100.0] * 4, [0.4] * 4, corr)
+    b, g, ns = book(True)
+    assert abs(float(g.compute_pv_analytically(model)) - 10.9551100513373) < 1e-10
+    sc = cases.SimulationController(ns, model, cases.RiskMetrics([cases.PVMetric()]), 1000000, 0, 1, cases.A, backend=hip)
+    res = sc.run_simulation()
+    (pa, ea), (pg, eg) = res.results[0][0][0], res.results[1][0][0]
+    assert ea < 0.004 and abs(pa - 12.60) < 0.02 and abs(pg - 10.9551100513373) < 0.02 + 3 * eg, (pa, ea, pg, eg)
