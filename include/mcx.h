@@ -157,7 +157,9 @@ typedef struct {
     double  sign;          /* +1 call / -1 put                                                                   */
     double  aux[4];        /* EXPO_BS: sigma, rate, remaining maturity.  OPTION: aux[0] = basket aggregation mode
                               (0: value = sum w_j atom_j; 1: geometric exp(sum w_j log(atom_j + 1e-10)); 2: arithmetic payoff
-                              - geometric payoff + aux[1], the control variate of basket_option.py:75-82)             */
+                              - geometric payoff + aux[1], the control variate of basket_option.py:75-82;
+                              3: binary payoff aux[1] * ind(sign * (value - strike)) with the fuzzy indicator
+                              clamp((x + aux[2]) / (2 aux[2]), 0, 1) of maths.py:3-9, binary_option.py:38-43)          */
 } mcx_event;
 
 typedef struct {

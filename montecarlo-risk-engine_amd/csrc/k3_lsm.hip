@@ -40,6 +40,16 @@ __device__ __forceinline__ double k3_cash_event(const DevEvent& e, const K3Args&
 {
     const double num = dev_atom(e.num, a.paths, D, a.ld, i);
     double common = 0.0, own = 0.0, glog = 0.0;
+    if (e.kind == MCX_EV_OPTION && e.aux[0] == 3.0) {                     // binary payoff (binary_option.py:38-43): fuzzy indicator
+        double val = 0.0;
+        AtomCache bc = {-1, -1, 0.0};
+        for (int j = e.term_begin; j < e.term_end; ++j) {
+            const DevTerm tm = ldk_struct(&a.terms[j]);
+            val = fma(tm.w, dev_atom_cached(tm.atom, a.paths, D, a.ld, i, bc), val);
+        }
+        const double dot = fmin(fmax((val - e.strike + e.aux[2]) / (2.0 * e.aux[2]), 0.0), 1.0);
+        return e.aux[1] * (e.sign > 0.0 ? dot : 1.0 - dot) / num;
+    }
     const bool basket = e.kind == MCX_EV_OPTION && e.aux[0] != 0.0;       // geometric aggregate needed (basket_option.py:56-82)
     AtomCache ac = {-1, -1, 0.0};
     for (int j = e.term_begin; j < e.term_end; ++j) {

@@ -247,7 +247,7 @@ __device__ __forceinline__ void kf_on_date(const FusedArgs& a, int t, int64_t i,
             for (int j = e.term_begin; j < e.term_end; ++j) {
                 const double av = f_atom<NREG>(terms[j].atom, reg);
                 val = fma(terms[j].w, av, val);
-                if (basket) glog = fma(terms[j].w, mcx_log(av + 1e-10), glog);
+                if (basket == 1 || basket == 2) glog = fma(terms[j].w, mcx_log(av + 1e-10), glog);
             }
             if (e.kind == MCX_EV_CASHFLOW) {
                 v = val * inv_num;
@@ -255,7 +255,10 @@ __device__ __forceinline__ void kf_on_date(const FusedArgs& a, int t, int64_t i,
                 const double imm = fmax(e.sign * (val - e.strike), 0.0);
                 if (e.kind == MCX_EV_OPTION) {
                     v = imm * inv_num;
-                    if (basket) {
+                    if (basket == 3) {                                   // binary payoff: fuzzy indicator (binary_option.py:38-43)
+                        const double dot = fmin(fmax((val - e.strike + ev.aux[2]) / (2.0 * ev.aux[2]), 0.0), 1.0);
+                        v = ev.aux[1] * (e.sign > 0.0 ? dot : 1.0 - dot) * inv_num;
+                    } else if (basket) {
                         const double geo = fmax(e.sign * (mcx_exp(glog) - e.strike), 0.0);
                         v = (basket == 1 ? geo : imm - geo + ev.aux[1]) * inv_num;
                     }

@@ -30,6 +30,8 @@ class ProductFamily(Enum):
     VANILLA_TERMINAL_OPTION = "vanilla_terminal_option"
     BERMUDAN_EXERCISE = "bermudan_exercise"
     BASKET_TERMINAL_PAYOFF = "basket_terminal_payoff"
+    BINARY_TERMINAL_PAYOFF = "binary_terminal_payoff"
+    ASIAN_PATH_TERMINAL = "asian_path_terminal"
 
 
 @dataclass
@@ -43,6 +45,7 @@ class CashEvent:
     x_asset: str | None = None      # EXERCISE: explanatory SPOT asset
     reg_idx: int | None = None      # EXERCISE: index into product.regression_coeffs (None: continuation 0)
     aux: tuple = (0.0, 0.0, 0.0, 0.0)   # OPTION: basket aggregation mode + control-variate constant (include/mcx.h)
+    num_time: float | None = None       # date whose numeraire normalises the event (default: the event's own date)
 
 
 class Product:

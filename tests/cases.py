@@ -22,6 +22,8 @@ from mcx.models.model_config import ModelConfig
 from mcx.models.vasicek import VasicekModel
 from mcx.products.basket_option import BasketOption, BasketOptionType
 from mcx.products.bermudan_option import AmericanOption, BermudanOption
+from mcx.products.binary_option import BinaryOption
+from mcx.products.asian_option import AsianOption, AsianAveragingType
 from mcx.products.bond import Bond
 from mcx.products.equity import Equity
 from mcx.products.european_option import EuropeanOption
@@ -168,6 +170,16 @@ def basket_multi():
     return _baskets(ids, True), model, RiskMetrics([PVMetric()])
 
 
+def binary_asian():
+    model = BlackScholesModel(0, 100.0, 0.03, 0.25)
+    prods = [BinaryOption(1.0, 100.5, 10.0, OptionType.CALL), BinaryOption(0.75, 99.0, 5.0, OptionType.PUT),
+             AsianOption(0.0, 1.0, 100.0, 5, OptionType.CALL, AsianAveragingType.ARITHMETIC),
+             AsianOption(0.25, 1.25, 102.0, 5, OptionType.PUT, AsianAveragingType.GEOMETRIC)]
+    for k, p in enumerate(prods):
+        p.name = f"p{k}"
+    return [NettingSet(name=p.name, products=[p]) for p in prods], model, RiskMetrics([PVMetric()])
+
+
 def bs_european_exposure():
     model = BlackScholesModel(0, 100.0, 0.03, 0.25)
     c = EuropeanOption(Equity(), 1.0, 95.0, OptionType.CALL); c.name = "call"
@@ -200,6 +212,8 @@ CASES = {
     "basket_model_config_euler": (basket_model_config, 0, 1024, 4, E, False),
     "basket_multi": (basket_multi, 0, 1024, 2, A, False),
     "basket_multi_euler": (basket_multi, 0, 1024, 3, E, False),
+    "binary_asian": (binary_asian, 0, 1024, 2, A, False),
+    "binary_asian_euler": (binary_asian, 0, 1024, 3, E, False),
     # sensitivities through the LSM regression; the fixtures hold only the reference gradients, draws = the base case's
     "irs_cva_aad": (irs_cva, 1024, 1024, 2, E, True),
     "mixed_cva_aad": (mixed_cva, 512, 512, 2, E, True),

@@ -40,6 +40,8 @@ from models.model_config import ModelConfig
 from models.vasicek import VasicekModel
 from products.basket_option import BasketOption, BasketOptionType
 from products.bermudan_option import AmericanOption, BermudanOption
+from products.binary_option import BinaryOption
+from products.asian_option import AsianOption, AsianAveragingType
 from products.bond import Bond
 from products.equity import Equity
 from products.european_option import EuropeanOption, OptionType
@@ -462,6 +464,17 @@ def case_basket_multi():
     return _baskets(ids, True), model, RiskMetrics([PVMetric()])
 
 
+def case_binary_asian():
+    """fuzzy binary payoffs (binary_option.py:38-43) and Asian averages incl. the first-date numeraire (asian_option.py:76-90)"""
+    model = BlackScholesModel(0, 100.0, 0.03, 0.25)
+    prods = [BinaryOption(1.0, 100.5, 10.0, OptionType.CALL), BinaryOption(0.75, 99.0, 5.0, OptionType.PUT),
+             AsianOption(0.0, 1.0, 100.0, 5, OptionType.CALL, AsianAveragingType.ARITHMETIC),
+             AsianOption(0.25, 1.25, 102.0, 5, OptionType.PUT, AsianAveragingType.GEOMETRIC)]
+    for k, p in enumerate(prods):
+        p.name = f"p{k}"
+    return [NettingSet(name=p.name, products=[p]) for p in prods], model, RiskMetrics([PVMetric()])
+
+
 def case_bs_european_exposure():
     """analytic Black-Scholes exposure path (european_option.py:123-145, controller.py:430-437): no regression"""
     model = BlackScholesModel(0, 100.0, 0.03, 0.25)
@@ -475,10 +488,8 @@ def case_bs_european_exposure():
 def main():
     torch.set_num_threads(4)
     if len(sys.argv) > 1 and sys.argv[1] == "new":
-        run_controller_case("basket_model_config", case_basket_model_config, 0, 1024, 2, SimulationScheme.ANALYTICAL)
-        run_controller_case("basket_model_config_euler", case_basket_model_config, 0, 1024, 4, SimulationScheme.EULER)
-        run_controller_case("basket_multi", case_basket_multi, 0, 1024, 2, SimulationScheme.ANALYTICAL)
-        run_controller_case("basket_multi_euler", case_basket_multi, 0, 1024, 3, SimulationScheme.EULER)
+        run_controller_case("binary_asian", case_binary_asian, 0, 1024, 2, SimulationScheme.ANALYTICAL)
+        run_controller_case("binary_asian_euler", case_binary_asian, 0, 1024, 3, SimulationScheme.EULER)
         return
     gen_steps()
     gen_paths_mc4()
@@ -507,6 +518,8 @@ def main():
     run_controller_case("basket_model_config_euler", case_basket_model_config, 0, 1024, 4, E)
     run_controller_case("basket_multi", case_basket_multi, 0, 1024, 2, A)
     run_controller_case("basket_multi_euler", case_basket_multi, 0, 1024, 3, E)
+    run_controller_case("binary_asian", case_binary_asian, 0, 1024, 2, A)
+    run_controller_case("binary_asian_euler", case_binary_asian, 0, 1024, 3, E)
 
 
 if __name__ == "__main__":
