@@ -159,7 +159,10 @@ typedef struct {
                               (0: value = sum w_j atom_j; 1: geometric exp(sum w_j log(atom_j + 1e-10)); 2: arithmetic payoff
                               - geometric payoff + aux[1], the control variate of basket_option.py:75-82;
                               3: binary payoff aux[1] * ind(sign * (value - strike)) with the fuzzy indicator
-                              clamp((x + aux[2]) / (2 aux[2]), 0, 1) of maths.py:3-9, binary_option.py:38-43)          */
+                              clamp((x + aux[2]) / (2 aux[2]), 0, 1) of maths.py:3-9, binary_option.py:38-43;
+                              4: discretely monitored barrier option (barrier_option.py:60-125): the terms are the
+                              monitored spots, x_atom the spot at maturity, aux[1] / aux[2] the barrier levels,
+                              aux[3] = type1 + 8 * type2 (1 up-out, 2 down-out, 3 up-in, 4 down-in; type2 0 = none))   */
 } mcx_event;
 
 typedef struct {

@@ -41,6 +41,18 @@ __device__ __forceinline__ double dev_cash_event(const DevEvent& e, const DevTer
 {
     const double num = dev_atom(e.num, paths, D, ld, i);
     double common = 0.0, own = 0.0, glog = 0.0;
+    if (e.kind == MCX_EV_OPTION && e.aux[0] == 4.0) {                     // barrier option, discrete monitoring (barrier_option.py:60-125)
+        double mx = -1.0e300, mn = 1.0e300;
+        AtomCache bc = {-1, -1, 0.0};
+        for (int j = e.term_begin; j < e.term_end; ++j) {
+            const double s = dev_atom_cached(ldk_struct(&terms[j]).atom, paths, D, ld, i, bc);
+            mx = fmax(mx, s); mn = fmin(mn, s);
+        }
+        const int types = (int)e.aux[3];
+        double pay = fmax(e.sign * (dev_atom(e.x, paths, D, ld, i) - e.strike), 0.0) * dev_barrier_ind(types & 7, e.aux[1], mx, mn);
+        if (types >> 3) pay *= dev_barrier_ind(types >> 3, e.aux[2], mx, mn);
+        return pay / num;
+    }
     if (e.kind == MCX_EV_OPTION && e.aux[0] == 3.0) {                     // binary payoff (binary_option.py:38-43): fuzzy indicator
         double val = 0.0;
         AtomCache bc = {-1, -1, 0.0};

@@ -70,6 +70,9 @@ extern "C" int mcx_book_create(mcx_handle* h, const mcx_book_desc* d, mcx_book**
             MCX_FAIL(h, -3, "mcx_book_create: event %d coefficient offset", i);
         if ((e.kind == MCX_EV_EXERCISE && e.coeff_off >= 0 && e.x_atom < 0) || (e.kind >= MCX_EV_EXPO_POLY && e.x_atom < 0))
             MCX_FAIL(h, -3, "mcx_book_create: event %d needs an explanatory atom", i);
+        if (e.kind == MCX_EV_OPTION && e.aux[0] == 4.0 && (e.x_atom < 0 || ((int)e.aux[3] & 7) < 1 || ((int)e.aux[3] & 7) > 4 || ((int)e.aux[3] >> 3) > 4))
+            MCX_FAIL(h, -3, "mcx_book_create: barrier event %d needs the maturity spot in x_atom and barrier types in 1..4", i);
+        if (e.kind == MCX_EV_OPTION && e.aux[0] == 3.0 && !(e.aux[2] > 0.0)) MCX_FAIL(h, -3, "mcx_book_create: binary event %d needs eps > 0", i);
         if (e.kind >= MCX_EV_EXPO_POLY && (e.expo_row < 0 || e.expo_row >= d->n_expo_rows)) MCX_FAIL(h, -3, "mcx_book_create: event %d row", i);
     }
     for (int p = 0; p < d->n_products; ++p) {

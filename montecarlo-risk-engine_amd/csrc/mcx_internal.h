@@ -219,6 +219,14 @@ __device__ __forceinline__ double dev_unsec(const DevUnsec& u, const double* __r
     return e - coll;
 }
 
+// barrier indicator of one barrier level (barrier_option.py:77-125): fuzzy "max below" / "min above" with the default
+// eps = 0.05 of maths.py:8; type 1 up-and-out, 2 down-and-out, 3 up-and-in, 4 down-and-in
+__device__ __forceinline__ double dev_barrier_ind(int type, double b, double mx, double mn)
+{
+    const double below = fmin(fmax((b - mx + 0.05) / 0.1, 0.0), 1.0), above = fmin(fmax((mn - b + 0.05) / 0.1, 0.0), 1.0);
+    return type == 1 ? below : type == 2 ? above : type == 3 ? 1.0 - below : 1.0 - above;
+}
+
 // host-side helpers implemented in mcx_api.hip
 int mcx_upload_unsec(mcx_handle* h, const mcx_unsecured_desc* u, DevUnsec* out, int32_t** d_tmp, hipStream_t s);
 int mcx_finish_acc(mcx_handle* h, const double* d_partials, int n_records, int n_blocks, double n_paths,

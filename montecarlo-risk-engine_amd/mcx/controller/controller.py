@@ -224,7 +224,8 @@ class SimulationController:
             def emit_cash(ce):
                 nt = ce.time if ce.num_time is None else ce.num_time
                 num = comp.atom(AtomicRequest(AtomicRequestType.NUMERAIRE, nt), "numeraire", nt)
-                x = comp.atom(AtomicRequest(AtomicRequestType.SPOT), ce.x_asset, ce.time) if ce.kind == _abi.EV_EXERCISE else -1
+                has_x = ce.kind == _abi.EV_EXERCISE or ce.x_time is not None or ce.x_asset is not None       # (an asset id may be None)
+                x = comp.atom(AtomicRequest(AtomicRequestType.SPOT), ce.x_asset, ce.time if ce.x_time is None else ce.x_time) if has_x else -1
                 co = -1 if ce.reg_idx is None else self._reg_coeff_base[p_i] + ce.reg_idx * S * K
                 return comp.add_event(ce.kind, comp.tidx(ce.time), num, x, comp.add_terms(ce.terms), co, -1, ce.strike, ce.sign, ce.aux)
 

@@ -31,6 +31,7 @@ class ProductFamily(Enum):
     BERMUDAN_EXERCISE = "bermudan_exercise"
     BASKET_TERMINAL_PAYOFF = "basket_terminal_payoff"
     BINARY_TERMINAL_PAYOFF = "binary_terminal_payoff"
+    BARRIER_PATH_TERMINAL = "barrier_path_terminal"
     ASIAN_PATH_TERMINAL = "asian_path_terminal"
 
 
@@ -46,6 +47,7 @@ class CashEvent:
     reg_idx: int | None = None      # EXERCISE: index into product.regression_coeffs (None: continuation 0)
     aux: tuple = (0.0, 0.0, 0.0, 0.0)   # OPTION: basket aggregation mode + control-variate constant (include/mcx.h)
     num_time: float | None = None       # date whose numeraire normalises the event (default: the event's own date)
+    x_time: float | None = None         # date at which x_asset's spot is read (default: the event's own date)
 
 
 class Product:

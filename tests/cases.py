@@ -23,6 +23,7 @@ from mcx.models.vasicek import VasicekModel
 from mcx.products.basket_option import BasketOption, BasketOptionType
 from mcx.products.bermudan_option import AmericanOption, BermudanOption
 from mcx.products.binary_option import BinaryOption
+from mcx.products.barrier_option import BarrierOption, BarrierOptionType
 from mcx.products.asian_option import AsianOption, AsianAveragingType
 from mcx.products.bond import Bond
 from mcx.products.equity import Equity
@@ -180,6 +181,18 @@ def binary_asian():
     return [NettingSet(name=p.name, products=[p]) for p in prods], model, RiskMetrics([PVMetric()])
 
 
+def barrier():
+    model = BlackScholesModel(0, 100.0, 0.03, 0.25)
+    B = BarrierOptionType
+    prods = [BarrierOption(0.0, 1.0, 100.0, 6, OptionType.CALL, 125.0, B.UPANDOUT),
+             BarrierOption(0.0, 1.0, 105.0, 6, OptionType.PUT, 90.0, B.DOWNANDIN),
+             BarrierOption(0.2, 1.2, 95.0, 5, OptionType.CALL, 85.0, B.DOWNANDOUT, 130.0, B.UPANDOUT),
+             BarrierOption(0.0, 0.8, 100.0, 5, OptionType.PUT, 110.0, B.UPANDIN, 80.0, B.DOWNANDOUT)]
+    for k, p in enumerate(prods):
+        p.name = f"b{k}"
+    return [NettingSet(name=p.name, products=[p]) for p in prods], model, RiskMetrics([PVMetric()])
+
+
 def bs_european_exposure():
     model = BlackScholesModel(0, 100.0, 0.03, 0.25)
     c = EuropeanOption(Equity(), 1.0, 95.0, OptionType.CALL); c.name = "call"
@@ -214,6 +227,8 @@ CASES = {
     "basket_multi_euler": (basket_multi, 0, 1024, 3, E, False),
     "binary_asian": (binary_asian, 0, 1024, 2, A, False),
     "binary_asian_euler": (binary_asian, 0, 1024, 3, E, False),
+    "barrier": (barrier, 0, 2048, 2, A, False),
+    "barrier_euler": (barrier, 0, 2048, 3, E, False),
     # sensitivities through the LSM regression; the fixtures hold only the reference gradients, draws = the base case's
     "irs_cva_aad": (irs_cva, 1024, 1024, 2, E, True),
     "mixed_cva_aad": (mixed_cva, 512, 512, 2, E, True),

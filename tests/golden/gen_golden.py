@@ -41,6 +41,7 @@ from models.vasicek import VasicekModel
 from products.basket_option import BasketOption, BasketOptionType
 from products.bermudan_option import AmericanOption, BermudanOption
 from products.binary_option import BinaryOption
+from products.barrier_option import BarrierOption, BarrierOptionType
 from products.asian_option import AsianOption, AsianAveragingType
 from products.bond import Bond
 from products.equity import Equity
@@ -475,6 +476,19 @@ def case_binary_asian():
     return [NettingSet(name=p.name, products=[p]) for p in prods], model, RiskMetrics([PVMetric()])
 
 
+def case_barrier():
+    """discretely monitored single / double barriers with fuzzy indicators (barrier_option.py:60-125)"""
+    model = BlackScholesModel(0, 100.0, 0.03, 0.25)
+    B = BarrierOptionType
+    prods = [BarrierOption(0.0, 1.0, 100.0, 6, OptionType.CALL, 125.0, B.UPANDOUT),
+             BarrierOption(0.0, 1.0, 105.0, 6, OptionType.PUT, 90.0, B.DOWNANDIN),
+             BarrierOption(0.2, 1.2, 95.0, 5, OptionType.CALL, 85.0, B.DOWNANDOUT, 130.0, B.UPANDOUT),
+             BarrierOption(0.0, 0.8, 100.0, 5, OptionType.PUT, 110.0, B.UPANDIN, 80.0, B.DOWNANDOUT)]
+    for k, p in enumerate(prods):
+        p.name = f"b{k}"
+    return [NettingSet(name=p.name, products=[p]) for p in prods], model, RiskMetrics([PVMetric()])
+
+
 def case_bs_european_exposure():
     """analytic Black-Scholes exposure path (european_option.py:123-145, controller.py:430-437): no regression"""
     model = BlackScholesModel(0, 100.0, 0.03, 0.25)
@@ -488,8 +502,8 @@ def case_bs_european_exposure():
 def main():
     torch.set_num_threads(4)
     if len(sys.argv) > 1 and sys.argv[1] == "new":
-        run_controller_case("binary_asian", case_binary_asian, 0, 1024, 2, SimulationScheme.ANALYTICAL)
-        run_controller_case("binary_asian_euler", case_binary_asian, 0, 1024, 3, SimulationScheme.EULER)
+        run_controller_case("barrier", case_barrier, 0, 2048, 2, SimulationScheme.ANALYTICAL)
+        run_controller_case("barrier_euler", case_barrier, 0, 2048, 3, SimulationScheme.EULER)
         return
     gen_steps()
     gen_paths_mc4()
@@ -520,6 +534,8 @@ def main():
     run_controller_case("basket_multi_euler", case_basket_multi, 0, 1024, 3, E)
     run_controller_case("binary_asian", case_binary_asian, 0, 1024, 2, A)
     run_controller_case("binary_asian_euler", case_binary_asian, 0, 1024, 3, E)
+    run_controller_case("barrier", case_barrier, 0, 2048, 2, A)
+    run_controller_case("barrier_euler", case_barrier, 0, 2048, 3, E)
 
 
 if __name__ == "__main__":
