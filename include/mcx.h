@@ -155,7 +155,8 @@ typedef struct {
     int32_t expo_row;      /* row of the exposure matrix (EXPO_*)                                                */
     double  strike;
     double  sign;          /* +1 call / -1 put                                                                   */
-    double  aux[4];        /* EXPO_BS: sigma, rate, remaining maturity.  OPTION: aux[0] = basket aggregation mode
+    double  aux[4];        /* EXPO_BS: sigma, rate, remaining maturity.  EXERCISE: aux[0] = 1: FlexiCall rule, exercise iff
+                              immediate + continuation(state-1) > continuation(state) (flexicall.py:118-133).  OPTION: aux[0] = basket aggregation mode
                               (0: value = sum w_j atom_j; 1: geometric exp(sum w_j log(atom_j + 1e-10)); 2: arithmetic payoff
                               - geometric payoff + aux[1], the control variate of basket_option.py:75-82;
                               3: binary payoff aux[1] * ind(sign * (value - strike)) with the fuzzy indicator

@@ -81,8 +81,13 @@ __device__ __forceinline__ double dev_cash_event(const DevEvent& e, const DevTer
     }
     if (e.kind == MCX_EV_OPTION) return imm / num;
     double cont = 0.0;                                        // MCX_EV_EXERCISE (bermudan_option.py:93-131)
-    if (e.coeff_off >= 0) cont = dev_poly(coeffs + e.coeff_off + s * K, K, dev_atom(e.x, paths, D, ld, i));
-    const bool ex = (imm > cont) && (s > 0);
+    double cont_ex = 0.0;                                     // continuation AFTER exercising (flexicall.py:118-133), aux[0] = 1
+    if (e.coeff_off >= 0) {
+        const double x = dev_atom(e.x, paths, D, ld, i);
+        cont = dev_poly(coeffs + e.coeff_off + s * K, K, x);
+        if (e.aux[0] == 1.0 && s > 0) cont_ex = dev_poly(coeffs + e.coeff_off + (s - 1) * K, K, x);
+    }
+    const bool ex = (imm + cont_ex > cont) && (s > 0);
     if (ex) s -= 1;
     return ex ? imm / num : 0.0;
 }

@@ -80,8 +80,13 @@ __device__ __forceinline__ double k3_cash_event(const DevEvent& e, const K3Args&
     }
     if (e.kind == MCX_EV_OPTION) return imm / num;
     double cont = 0.0;
-    if (e.coeff_off >= 0) cont = k3_poly(a.coeffs + e.coeff_off + s * a.n_basis, a.n_basis, dev_atom(e.x, a.paths, D, a.ld, i));
-    const bool ex = (imm > cont) && (s > 0);
+    double cont_ex = 0.0;                                     // flexicall.py:118-133 (aux[0] = 1)
+    if (e.coeff_off >= 0) {
+        const double x = dev_atom(e.x, a.paths, D, a.ld, i);
+        cont = k3_poly(a.coeffs + e.coeff_off + s * a.n_basis, a.n_basis, x);
+        if (e.aux[0] == 1.0 && s > 0) cont_ex = k3_poly(a.coeffs + e.coeff_off + (s - 1) * a.n_basis, a.n_basis, x);
+    }
+    const bool ex = (imm + cont_ex > cont) && (s > 0);
     if (ex) s -= 1;
     return ex ? imm / num : 0.0;
 }

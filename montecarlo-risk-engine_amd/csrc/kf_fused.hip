@@ -266,9 +266,14 @@ __device__ __forceinline__ void kf_on_date(const FusedArgs& a, int t, int64_t i,
                     int s = 0;
 #pragma unroll
                     for (int w = 0; w < NSTA; ++w) s = (e.sidx == w) ? est[w] : s;
-                    double cont = 0.0;
-                    if (e.coeff_off >= 0) cont = f_poly(a.coeffs + e.coeff_off + s * a.n_basis, a.n_basis, f_atom<NREG>(e.x, reg));
-                    const bool ex = (imm > cont) && (s > 0);
+                    double cont = 0.0, cont_ex = 0.0;
+                    if (e.coeff_off >= 0) {
+                        const double x = f_atom<NREG>(e.x, reg);
+                        cont = f_poly(a.coeffs + e.coeff_off + s * a.n_basis, a.n_basis, x);
+                        if (RFL((int)ev.aux[0]) == 1)            // FlexiCall: continuation after exercising (flexicall.py:118-133)
+                            cont_ex = s > 0 ? f_poly(a.coeffs + e.coeff_off + (s - 1) * a.n_basis, a.n_basis, x) : 0.0;
+                    }
+                    const bool ex = (imm + cont_ex > cont) && (s > 0);
                     v = ex ? imm * inv_num : 0.0;
 #pragma unroll
                     for (int w = 0; w < NSTA; ++w) est[w] = (e.sidx == w && ex) ? s - 1 : est[w];

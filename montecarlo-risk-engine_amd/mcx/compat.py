@@ -21,7 +21,7 @@ _MODULES = [
     "models.model", "models.model_config", "models.black_scholes", "models.heston", "models.vasicek", "models.cirpp",
     "models.hull_white", "models.black_scholes_multi",
     "products.product", "products.equity", "products.bond", "products.swap", "products.european_option",
-    "products.bermudan_option", "products.netting_set", "products.basket_option", "products.binary_option", "products.asian_option", "products.barrier_option",
+    "products.bermudan_option", "products.netting_set", "products.basket_option", "products.binary_option", "products.asian_option", "products.barrier_option", "products.flexicall",
     "request_interface.request_types", "request_interface.request_interface",
 ]
 

@@ -32,6 +32,7 @@ class ProductFamily(Enum):
     BASKET_TERMINAL_PAYOFF = "basket_terminal_payoff"
     BINARY_TERMINAL_PAYOFF = "binary_terminal_payoff"
     BARRIER_PATH_TERMINAL = "barrier_path_terminal"
+    FLEXICALL_EXERCISE = "flexicall_exercise"
     ASIAN_PATH_TERMINAL = "asian_path_terminal"
 
 

@@ -23,6 +23,7 @@ from mcx.models.vasicek import VasicekModel
 from mcx.products.basket_option import BasketOption, BasketOptionType
 from mcx.products.bermudan_option import AmericanOption, BermudanOption
 from mcx.products.binary_option import BinaryOption
+from mcx.products.flexicall import FlexiCall
 from mcx.products.barrier_option import BarrierOption, BarrierOptionType
 from mcx.products.asian_option import AsianOption, AsianAveragingType
 from mcx.products.bond import Bond
@@ -193,6 +194,17 @@ def barrier():
     return [NettingSet(name=p.name, products=[p]) for p in prods], model, RiskMetrics([PVMetric()])
 
 
+def flexicall():
+    model = BlackScholesModel(0, 100.0, 0.03, 0.25)
+    opts = [EuropeanOption(Equity(), 0.25 * (k + 1), 98.0 + 2.0 * k, OptionType.PUT) for k in range(5)]
+    fc = FlexiCall(opts, 2); fc.name = "flexi"
+    opts3 = [EuropeanOption(Equity(), 0.2 * (k + 1), 101.0 - k, OptionType.CALL) for k in range(4)]
+    fc3 = FlexiCall(opts3, 3); fc3.name = "flexi3"
+    tl = np.array([0.0, 0.25, 0.5, 0.75, 1.0, 1.25])
+    return [NettingSet(name="flexi", products=[fc]), NettingSet(name="flexi3", products=[fc3])], model, \
+        RiskMetrics([PVMetric(), EPEMetric()], exposure_timeline=tl)
+
+
 def bs_european_exposure():
     model = BlackScholesModel(0, 100.0, 0.03, 0.25)
     c = EuropeanOption(Equity(), 1.0, 95.0, OptionType.CALL); c.name = "call"
@@ -229,6 +241,7 @@ CASES = {
     "binary_asian_euler": (binary_asian, 0, 1024, 3, E, False),
     "barrier": (barrier, 0, 2048, 2, A, False),
     "barrier_euler": (barrier, 0, 2048, 3, E, False),
+    "flexicall": (flexicall, 2048, 1024, 1, A, False),
     # sensitivities through the LSM regression; the fixtures hold only the reference gradients, draws = the base case's
     "irs_cva_aad": (irs_cva, 1024, 1024, 2, E, True),
     "mixed_cva_aad": (mixed_cva, 512, 512, 2, E, True),

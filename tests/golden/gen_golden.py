@@ -41,6 +41,7 @@ from models.vasicek import VasicekModel
 from products.basket_option import BasketOption, BasketOptionType
 from products.bermudan_option import AmericanOption, BermudanOption
 from products.binary_option import BinaryOption
+from products.flexicall import FlexiCall
 from products.barrier_option import BarrierOption, BarrierOptionType
 from products.asian_option import AsianOption, AsianAveragingType
 from products.bond import Bond
@@ -489,6 +490,18 @@ def case_barrier():
     return [NettingSet(name=p.name, products=[p]) for p in prods], model, RiskMetrics([PVMetric()])
 
 
+def case_flexicall():
+    """k-right exercise machines (flexicall.py:104-143): LSM over (k+1) states, exposures via the regression"""
+    model = BlackScholesModel(0, 100.0, 0.03, 0.25)
+    opts = [EuropeanOption(Equity(), 0.25 * (k + 1), 98.0 + 2.0 * k, OptionType.PUT) for k in range(5)]
+    fc = FlexiCall(opts, 2); fc.name = "flexi"
+    opts3 = [EuropeanOption(Equity(), 0.2 * (k + 1), 101.0 - k, OptionType.CALL) for k in range(4)]
+    fc3 = FlexiCall(opts3, 3); fc3.name = "flexi3"
+    tl = np.array([0.0, 0.25, 0.5, 0.75, 1.0, 1.25])
+    return [NettingSet(name="flexi", products=[fc]), NettingSet(name="flexi3", products=[fc3])], model, \
+        RiskMetrics([PVMetric(), EPEMetric()], exposure_timeline=tl)
+
+
 def case_bs_european_exposure():
     """analytic Black-Scholes exposure path (european_option.py:123-145, controller.py:430-437): no regression"""
     model = BlackScholesModel(0, 100.0, 0.03, 0.25)
@@ -502,8 +515,7 @@ def case_bs_european_exposure():
 def main():
     torch.set_num_threads(4)
     if len(sys.argv) > 1 and sys.argv[1] == "new":
-        run_controller_case("barrier", case_barrier, 0, 2048, 2, SimulationScheme.ANALYTICAL)
-        run_controller_case("barrier_euler", case_barrier, 0, 2048, 3, SimulationScheme.EULER)
+        run_controller_case("flexicall", case_flexicall, 2048, 1024, 1, SimulationScheme.ANALYTICAL)
         return
     gen_steps()
     gen_paths_mc4()
@@ -536,6 +548,7 @@ def main():
     run_controller_case("binary_asian_euler", case_binary_asian, 0, 1024, 3, E)
     run_controller_case("barrier", case_barrier, 0, 2048, 2, A)
     run_controller_case("barrier_euler", case_barrier, 0, 2048, 3, E)
+    run_controller_case("flexicall", case_flexicall, 2048, 1024, 1, A)
 
 
 if __name__ == "__main__":
