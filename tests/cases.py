@@ -205,6 +205,51 @@ def flexicall():
         RiskMetrics([PVMetric(), EPEMetric()], exposure_timeline=tl)
 
 
+def _mixed_book_products(mod):
+    """every product family of the reference's large-book script (pv_performance_large_netting_set.py:86-233), a few of each;
+    `mod` supplies the classes (the reference's modules here, mcx's in tests/cases.py)"""
+    ids = [f"asset_{k}" for k in range(4)]
+    P = []
+    O, E = mod["OptionType"], mod["Equity"]
+    for i in range(6):
+        a = ids[i % 4]
+        P.append(mod["EuropeanOption"](E(a), [0.25, 0.5, 0.75, 1.0, 1.5, 2.0][i], [80.0, 90.0, 100.0, 110.0, 120.0][i % 5], O.CALL if i % 2 == 0 else O.PUT, asset_id=a))
+    for i in range(3):
+        p = mod["BinaryOption"]([0.5, 1.0, 1.5][i], [90.0, 100.0, 110.0][i], 8.0 + 2.0 * i, O.CALL if i % 2 == 0 else O.PUT, asset_id=ids[i % 4]); p.name = f"binary_{i}"; P.append(p)
+    bw = [[0.5, 0.3, 0.2, 0.0], [0.25, 0.25, 0.25, 0.25], [0.4, 0.35, 0.15, 0.10]]
+    for i in range(3):
+        k = 2 + i
+        w = bw[i][:k]
+        p = mod["BasketOption"]([0.75, 1.25, 2.0][i], ids[:k], [x / sum(w) for x in w], 95.0 + 5.0 * i, O.CALL if i % 2 == 0 else O.PUT,
+                                mod["BasketOptionType"].ARITHMETIC if i != 0 else mod["BasketOptionType"].GEOMETRIC, False); p.name = f"basket_{i}"; P.append(p)
+    for i in range(3):
+        p = mod["AsianOption"](0.0, [0.5, 1.0, 1.5][i], 88.0 + 6.0 * i, [8, 12, 18][i], O.CALL if i % 2 == 0 else O.PUT,
+                               mod["AsianAveragingType"].ARITHMETIC if i != 0 else mod["AsianAveragingType"].GEOMETRIC, asset_id=ids[(i + 1) % 4]); p.name = f"asian_{i}"; P.append(p)
+    for i in range(4):
+        p = mod["BarrierOption"](0.0, [0.5, 0.75, 1.25, 1.75][i], 85.0 + 7.5 * i, [8, 12, 18, 24][i], O.CALL if i % 3 != 0 else O.PUT,
+                                 [118.0, 125.0, 132.0, 140.0][i] + 2.0 * (i % 2), mod["BarrierOptionType"].UPANDOUT, asset_id=ids[i % 4]); p.name = f"barrier_{i}"; P.append(p)
+    for i in range(3):
+        a = ids[(i + 2) % 4]
+        p = mod["AmericanOption"](E(a), [0.75, 1.0, 1.5][i], [8, 12, 18][i], [80.0, 100.0, 120.0][i], O.PUT if i % 2 == 0 else O.CALL, asset_id=a); p.name = f"american_{i}"; P.append(p)
+    for i in range(3):
+        a = ids[i % 4]
+        mat, L = [1.0, 1.5, 2.0][i], [3, 4, 5][i]
+        und = [mod["EuropeanOption"](E(a), float(t), 90.0 + 6.0 * ((i + k) % 6), O.CALL, asset_id=a) for k, t in enumerate(np.linspace(mat / L, mat, L))]
+        p = mod["FlexiCall"](und, min(1 + i, L - 1), asset_id=a); p.name = f"flexicall_{i}"; P.append(p)
+    return ids, P
+
+
+def mixed_book_multi():
+    ids, P = _mixed_book_products(globals())
+    corr = np.full((4, 4), 0.35); np.fill_diagonal(corr, 1.0)
+    market = BlackScholesMulti(0.0, 0.03, ids, [95.0 + 7.5 * k for k in range(4)], [0.18 + 0.03 * k for k in range(4)], corr)
+    credit = CIRPPModel(0.0, "cp", HAZARDS, kappa=0.10, theta=0.01, volatility=0.02, y0=0.0001, deterministic=False)
+    model = ModelConfig([market, credit], inter_asset_correlation_matrix=[np.full((4, 1), 0.2)])
+    horizon = max(float(p.modeling_timeline[-1]) for p in P)
+    ns = [NettingSet(name="book", products=P, counterparty_id="cp", margin_period_of_risk=10 / 252)]
+    return ns, model, RiskMetrics([CVAMetric("cp", 0.4), EPEMetric()], exposure_timeline=np.linspace(0.0, horizon, 12))
+
+
 def bs_european_exposure():
     model = BlackScholesModel(0, 100.0, 0.03, 0.25)
     c = EuropeanOption(Equity(), 1.0, 95.0, OptionType.CALL); c.name = "call"
@@ -242,6 +287,7 @@ CASES = {
     "barrier": (barrier, 0, 2048, 2, A, False),
     "barrier_euler": (barrier, 0, 2048, 3, E, False),
     "flexicall": (flexicall, 2048, 1024, 1, A, False),
+    "mixed_book_multi": (mixed_book_multi, 128, 128, 1, E, False),
     # sensitivities through the LSM regression; the fixtures hold only the reference gradients, draws = the base case's
     "irs_cva_aad": (irs_cva, 1024, 1024, 2, E, True),
     "mixed_cva_aad": (mixed_cva, 512, 512, 2, E, True),

@@ -1,0 +1,131 @@
+#!/usr/bin/env python3
+"""Large mixed netting set CVA: the book of the reference's own performance script
+(tests/exposure_tests/cva_perfprmance_large_netting_set.py:69-148 with pv_tests/pv_performance_large_netting_set.py:86-233)
+— Europeans, binaries, baskets, Asians, barriers, Americans, FlexiCalls on a 4-asset BlackScholesMulti + CIR++ credit,
+10-day MPoR collateral, 80 exposure dates, 1000 + 1000 paths, one Euler step per date — WITHOUT the gas-storage products
+(out of scope).  Prints products/s like the reference script.
+
+    python tools/large_book.py [--scale 1.0] [--paths 1000] [--backend hip|oracle]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "montecarlo-risk-engine_amd"))
+
+from mcx.common.enums import SimulationScheme                                          # noqa: E402
+from mcx.controller.controller import SimulationController                            # noqa: E402
+from mcx.metrics.cva_metric import CVAMetric                                           # noqa: E402
+from mcx.metrics.risk_metrics import RiskMetrics                                       # noqa: E402
+from mcx.models.black_scholes_multi import BlackScholesMulti                           # noqa: E402
+from mcx.models.cirpp import CIRPPModel                                                # noqa: E402
+from mcx.models.model_config import ModelConfig                                        # noqa: E402
+from mcx.products.asian_option import AsianAveragingType, AsianOption                  # noqa: E402
+from mcx.products.barrier_option import BarrierOption, BarrierOptionType               # noqa: E402
+from mcx.products.basket_option import BasketOption, BasketOptionType                  # noqa: E402
+from mcx.products.bermudan_option import AmericanOption                                # noqa: E402
+from mcx.products.binary_option import BinaryOption                                    # noqa: E402
+from mcx.products.equity import Equity                                                 # noqa: E402
+from mcx.products.european_option import EuropeanOption                                # noqa: E402
+from mcx.products.flexicall import FlexiCall                                           # noqa: E402
+from mcx.products.netting_set import NettingSet                                        # noqa: E402
+from mcx.products.product import OptionType                                            # noqa: E402
+
+CP = "mixed_book_counterparty"
+HAZARDS = {0.5: 0.006402303360855854, 1.0: 0.01553038972325307, 2.0: 0.009729741230773657, 3.0: 0.015552544648116201,
+           4.0: 0.021196186202801115, 5.0: 0.02284319986706472, 7.0: 0.010111423894480876, 10.0: 0.00613267811172937,
+           15.0: 0.0036969930706003337, 20.0: 0.003791311459217732}
+
+
+def build_mixed_book(asset_ids, n_eur, n_bin, n_bas, n_asi, n_bar, n_ame, n_flx):
+    P = []
+    mats, strikes = [0.25, 0.5, 0.75, 1.0, 1.5, 2.0, 2.5, 3.0], [80.0, 90.0, 100.0, 110.0, 120.0]
+    for i in range(n_eur):
+        a = asset_ids[i % len(asset_ids)]
+        P.append(EuropeanOption(Equity(a), mats[i % 8], strikes[i % 5], OptionType.CALL if i % 2 == 0 else OptionType.PUT, asset_id=a))
+    for i in range(n_bin):
+        p = BinaryOption([0.5, 1.0, 1.5, 2.0][i % 4], [90.0, 100.0, 110.0][i % 3], 8.0 + 2.0 * (i % 4),
+                         OptionType.CALL if i % 2 == 0 else OptionType.PUT, asset_id=asset_ids[i % len(asset_ids)])
+        p.name = f"binary_{i}"; P.append(p)
+    bw = [[0.5, 0.3, 0.2, 0.0], [0.25, 0.25, 0.25, 0.25], [0.4, 0.35, 0.15, 0.10]]
+    for i in range(n_bas):
+        k = 2 + (i % min(3, len(asset_ids) - 1 if len(asset_ids) > 1 else 1))
+        w = bw[i % 3][:k]
+        p = BasketOption([0.75, 1.25, 2.0, 2.5][i % 4], asset_ids[:k], [x / sum(w) for x in w], 95.0 + 5.0 * (i % 5),
+                         OptionType.CALL if i % 2 == 0 else OptionType.PUT,
+                         BasketOptionType.ARITHMETIC if i % 3 != 0 else BasketOptionType.GEOMETRIC, False)
+        p.name = f"basket_{i}"; P.append(p)
+    for i in range(n_asi):
+        p = AsianOption(0.0, [0.5, 0.75, 1.0, 1.5, 2.0][i % 5], 88.0 + 6.0 * (i % 6), [8, 12, 18, 24][i % 4],
+                        OptionType.CALL if i % 2 == 0 else OptionType.PUT,
+                        AsianAveragingType.ARITHMETIC if i % 3 != 0 else AsianAveragingType.GEOMETRIC,
+                        asset_id=asset_ids[i % len(asset_ids)])
+        p.name = f"asian_{i}"; P.append(p)
+    for i in range(n_bar):
+        p = BarrierOption(0.0, [0.5, 0.75, 1.25, 1.75, 2.5, 3.0][i % 6], 85.0 + 7.5 * (i % 6), [8, 12, 18, 24, 36][i % 5],
+                          OptionType.CALL if i % 3 != 0 else OptionType.PUT, [118.0, 125.0, 132.0, 140.0][i % 4] + 2.0 * (i % 2),
+                          BarrierOptionType.UPANDOUT, asset_id=asset_ids[i % len(asset_ids)])
+        p.name = f"barrier_{i}"; P.append(p)
+    for i in range(n_ame):
+        a = asset_ids[i % len(asset_ids)]
+        p = AmericanOption(Equity(a), [0.75, 1.0, 1.5, 2.0, 2.5, 3.0][i % 6], [8, 12, 18, 24, 36, 48][i % 6],
+                           [80.0, 92.5, 100.0, 107.5, 120.0][i % 5], OptionType.PUT if i % 2 == 0 else OptionType.CALL, asset_id=a)
+        p.name = f"american_{i}"; P.append(p)
+    for i in range(n_flx):
+        a = asset_ids[i % len(asset_ids)]
+        mat, L = [1.0, 1.5, 2.0, 2.5][i % 4], [3, 4, 5][i % 3]
+        und = [EuropeanOption(Equity(a), float(t), 90.0 + 6.0 * ((i + k) % 6), OptionType.CALL, asset_id=a)
+               for k, t in enumerate(np.linspace(mat / L, mat, L))]
+        p = FlexiCall(und, min(1 + (i % 3), L - 1), asset_id=a)
+        p.name = f"flexicall_{i}"; P.append(p)
+    return P
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scale", type=float, default=1.0, help="fraction of the reference script's 4,990 non-storage products")
+    ap.add_argument("--paths", type=int, default=1000)
+    ap.add_argument("--exposure-points", type=int, default=80)
+    ap.add_argument("--backend", default="hip", choices=["hip", "oracle"])
+    ap.add_argument("--repeat", type=int, default=2)
+    args = ap.parse_args()
+    if args.backend == "hip":
+        from mcx import _native
+        be = _native.HipBackend(0)
+    else:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from oracle_backend import OracleBackend
+        be = OracleBackend()
+    ids = [f"asset_{k}" for k in range(4)]
+    counts = [max(1, int(round(c * args.scale))) for c in (3940, 100, 100, 200, 400, 180, 70)]
+    for rep in range(args.repeat):
+        corr = np.full((4, 4), 0.35); np.fill_diagonal(corr, 1.0)
+        market = BlackScholesMulti(0.0, 0.03, ids, [95.0 + 7.5 * k for k in range(4)], [0.18 + 0.03 * k for k in range(4)], corr)
+        credit = CIRPPModel(0.0, CP, HAZARDS, kappa=0.10, theta=0.01, volatility=0.02, y0=0.0001, deterministic=False)
+        model = ModelConfig([market, credit], inter_asset_correlation_matrix=[np.full((4, 1), 0.2)])
+        products = build_mixed_book(ids, *counts)
+        horizon = max(float(p.modeling_timeline[-1]) for p in products)
+        tl = np.linspace(0.0, horizon, args.exposure_points)
+        ns = NettingSet(name="mixed_state_dependent_book_cva", products=products, counterparty_id=CP, margin_period_of_risk=10 / 252)
+        cva = CVAMetric(counterparty_id=CP, recovery_rate=0.4)
+        t0 = time.perf_counter()
+        sc = SimulationController([ns], model, RiskMetrics([cva], exposure_timeline=tl), args.paths, args.paths, 1,
+                                  SimulationScheme.EULER, backend=be)
+        t1 = time.perf_counter()
+        res = sc.run_simulation()
+        be.synchronize() if hasattr(be, "synchronize") else None
+        t2 = time.perf_counter()
+        out = dict(products=len(products), counts=counts, paths=args.paths, exposure_points=args.exposure_points,
+                   timeline_size=int(sc.simulation_timeline.numel()), construct_s=t1 - t0, run_s=t2 - t1,
+                   products_per_second=len(products) / (t2 - t1), timings=sc.timings,
+                   cva=float(res.get_results(ns.get_name(), cva.get_name(), evaluation_idx=0)),
+                   mc_error=float(res.get_mc_error(ns.get_name(), cva.get_name(), evaluation_idx=0)), backend=args.backend)
+        print(json.dumps(out, default=float), flush=True)
+
+
+if __name__ == "__main__":
+    main()
