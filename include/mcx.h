@@ -321,6 +321,22 @@ int  mcx_lsm_step(mcx_handle* h, const mcx_book* book, int32_t product, int32_t 
                   const double* d_paths, int64_t n_paths, int64_t ld,
                   double* d_W, int64_t ld_w, double* d_moments, int32_t flags, void* stream);
 
+/* Product-batched LSM step (books of thousands of products: tests/exposure_tests/cva_perfprmance_large_netting_set.py): the
+ * step of mcx_lsm_step for n_jobs products with the SAME number of exercise states in one launch.  Job j uses the cashflow
+ * cache block d_W + w_offset (layout [n_states][ld_w]) and returns its moments in h_moments[j * NM .. ), NM = (2K-1) + S*K
+ * (host memory; the call synchronises).  Replaces the per-product loop of controller.py:289-291. */
+typedef struct {
+    int32_t product, roll_begin, roll_end, num_atom, x_atom, reserved;
+    int64_t w_offset;
+    double  shift, scale;
+} mcx_lsm_job;
+int  mcx_lsm_step_batch(mcx_handle* h, const mcx_book* book, const mcx_lsm_job* h_jobs, int32_t n_jobs, int32_t n_states,
+                        const double* d_paths, int64_t n_paths, int64_t ld, double* d_W, int64_t ld_w,
+                        double* h_moments, int32_t flags, void* stream);
+/* coeffs[h_offsets[j] + q] = h_values[j * len + q], q < len, for n blocks in one call (the batched form of mcx_book_set_coeffs) */
+int  mcx_book_set_coeffs_batch(mcx_handle* h, mcx_book* book, const int64_t* h_offsets, int32_t n, int32_t len,
+                               const double* h_values, void* stream);
+
 /* K4 — reductions. Every output record is an mcx_acc (host memory, valid on return).
  * mcx_reduce_vector  : PVMetric on cfs (pv_metric.py:17-18)                                   h_out[1]
  * mcx_reduce_profiles: EPE / ENE per metric date (epe_metric.py:11-16, ene_metric.py:11-16)   h_out[2*n_dates] = {pos_m, neg_m}

@@ -8,6 +8,8 @@
 //
 // One lane = one path; the event program (products -> events -> terms) is wave-uniform, so it is walked with scalar
 // loads and scalar branches; all HBM accesses are 512-byte coalesced rows of the [date][state][path] layout.
+#include <algorithm>
+
 #include "mcx_internal.h"
 
 namespace {
@@ -23,6 +25,9 @@ struct K2Args {
     double* __restrict__ expo;
     int64_t n, ld, ld_out;
     int32_t n_products, n_basis, n_state, n_expo_rows, want_cfs, want_expo;
+    // product-chunked mode (big books on few paths): blockIdx.y = chunk of `chunk_products` consecutive products, each chunk
+    // ACCUMULATES into its own zero-initialised [n_ns][*][ld_out] image (cfs / expo then point at the chunk images)
+    int32_t chunk_products, n_netting_sets;
 };
 
 __device__ __forceinline__ double dev_poly(const double* __restrict__ c, int K, double x)
@@ -100,11 +105,20 @@ __global__ __launch_bounds__(MCX_BLOCK) void k2_eval_book(const K2Args a)
     const int K = a.n_basis;
     int cur_ns = -1;
     double acc_ns = 0.0;
-    for (int p = 0; p < a.n_products; ++p) {
+    const bool chunked = a.chunk_products > 0;
+    const int p_begin = chunked ? (int)blockIdx.y * a.chunk_products : 0;
+    const int p_end = chunked ? min(p_begin + a.chunk_products, a.n_products) : a.n_products;
+    double* __restrict__ cfs_out = a.cfs;
+    double* __restrict__ expo_out = a.expo;
+    if (chunked) {
+        if (cfs_out) cfs_out += (int64_t)blockIdx.y * a.n_netting_sets * a.ld_out;
+        if (expo_out) expo_out += (int64_t)blockIdx.y * a.n_netting_sets * a.n_expo_rows * a.ld_out;
+    }
+    for (int p = p_begin; p < p_end; ++p) {
         const DevProduct pr = ldk_struct(&a.products[p]);
         if (pr.ev_end == pr.ev_begin) continue;              // analytically valued product: no Monte-Carlo events
         if (pr.netting_set != cur_ns) {
-            if (cur_ns >= 0 && a.want_cfs) a.cfs[(int64_t)cur_ns * a.ld_out + i] = acc_ns;
+            if (cur_ns >= 0 && a.want_cfs) cfs_out[(int64_t)cur_ns * a.ld_out + i] = acc_ns;
             cur_ns = pr.netting_set;
             acc_ns = 0.0;
         }
@@ -133,14 +147,24 @@ __global__ __launch_bounds__(MCX_BLOCK) void k2_eval_book(const K2Args a)
                                                       : Kx * df * dev_norm_cdf(-d2) - spot * dev_norm_cdf(-d1);
                     v = price / num;
                 }
-                double* dst = a.expo + ((int64_t)pr.netting_set * a.n_expo_rows + e.row) * a.ld_out + i;
-                if (e.flags & 1) *dst += v;
+                double* dst = expo_out + ((int64_t)pr.netting_set * a.n_expo_rows + e.row) * a.ld_out + i;
+                if ((e.flags & 1) || chunked) *dst += v;
                 else *dst = v;
             }
         }
         acc_ns += acc;
     }
-    if (cur_ns >= 0 && a.want_cfs) a.cfs[(int64_t)cur_ns * a.ld_out + i] = acc_ns;
+    if (cur_ns >= 0 && a.want_cfs) cfs_out[(int64_t)cur_ns * a.ld_out + i] = acc_ns;
+}
+
+// out[j] = sum over chunks of part[c][j] in chunk order (deterministic)
+__global__ __launch_bounds__(MCX_BLOCK) void k2_sum_chunks(const double* __restrict__ part, int n_chunks, int64_t count, double* __restrict__ out)
+{
+    const int64_t j = (int64_t)blockIdx.x * MCX_BLOCK + threadIdx.x;
+    if (j >= count) return;
+    double s = 0.0;
+    for (int c = 0; c < n_chunks; ++c) s += part[(int64_t)c * count + j];
+    out[j] = s;
 }
 
 __global__ __launch_bounds__(MCX_BLOCK) void k2_resolve(const DevAtom* __restrict__ atoms, const int32_t* __restrict__ ids, int n_ids,
@@ -173,9 +197,39 @@ extern "C" int mcx_eval_book(mcx_handle* h, const mcx_book* b, const double* d_p
     a.paths = d_paths; a.cfs = d_cfs; a.expo = d_expo; a.n = n_paths; a.ld = ld; a.ld_out = ld_out;
     a.n_products = b->n_products; a.n_basis = b->n_basis; a.n_state = b->n_state; a.n_expo_rows = b->n_expo_rows;
     a.want_cfs = b->want_cfs; a.want_expo = b->want_expo;
+    a.chunk_products = 0; a.n_netting_sets = b->n_netting_sets;
     const int grid = (int)((n_paths + MCX_BLOCK - 1) / MCX_BLOCK);
-    hipLaunchKernelGGL(k2_eval_book, dim3(grid), dim3(MCX_BLOCK), 0, s, a);
-    MCX_HIP(h, hipGetLastError());
+    // Few paths x many products (the reference's 5,000-product books run on ~1,000 paths): the path grid alone leaves the
+    // chip empty (4 workgroups) while every lane walks ~10^6 events.  Split the PRODUCT list over blockIdx.y instead; each
+    // chunk accumulates into its own image, a second kernel adds the images in chunk order.
+    const size_t img = (size_t)b->n_netting_sets * ((b->want_expo ? b->n_expo_rows : 0) + (b->want_cfs ? 1 : 0)) * (size_t)ld_out * sizeof(double);
+    int n_chunks = 1;
+    if (grid < 64 && b->n_products >= 64 && ld_out == n_paths && img > 0) {
+        n_chunks = std::min(std::min(1024 / grid, b->n_products / 8), (int)std::max<size_t>(1, ((size_t)512 << 20) / img));
+        if (n_chunks < 2) n_chunks = 1;
+    }
+    if (n_chunks == 1) {
+        hipLaunchKernelGGL(k2_eval_book, dim3(grid), dim3(MCX_BLOCK), 0, s, a);
+        MCX_HIP(h, hipGetLastError());
+        return 0;
+    }
+    a.chunk_products = (b->n_products + n_chunks - 1) / n_chunks;
+    n_chunks = (b->n_products + a.chunk_products - 1) / a.chunk_products;
+    const int64_t n_cfs = b->want_cfs ? (int64_t)b->n_netting_sets * ld_out : 0;
+    const int64_t n_expo = b->want_expo ? (int64_t)b->n_netting_sets * b->n_expo_rows * ld_out : 0;
+    double* d_part = nullptr;
+    MCX_HIP(h, hipMalloc(&d_part, sizeof(double) * (size_t)n_chunks * (size_t)(n_cfs + n_expo)));
+    MCX_HIP(h, hipMemsetAsync(d_part, 0, sizeof(double) * (size_t)n_chunks * (size_t)(n_cfs + n_expo), s));
+    a.cfs = n_cfs ? d_part : nullptr;
+    a.expo = n_expo ? d_part + (size_t)n_chunks * n_cfs : nullptr;
+    hipLaunchKernelGGL(k2_eval_book, dim3(grid, n_chunks), dim3(MCX_BLOCK), 0, s, a);
+    if (n_cfs) hipLaunchKernelGGL(k2_sum_chunks, dim3((unsigned)((n_cfs + MCX_BLOCK - 1) / MCX_BLOCK)), dim3(MCX_BLOCK), 0, s, a.cfs, n_chunks, n_cfs, d_cfs);
+    if (n_expo) hipLaunchKernelGGL(k2_sum_chunks, dim3((unsigned)((n_expo + MCX_BLOCK - 1) / MCX_BLOCK)), dim3(MCX_BLOCK), 0, s, a.expo, n_chunks, n_expo, d_expo);
+    hipError_t e1 = hipGetLastError();
+    hipError_t e2 = hipStreamSynchronize(s);
+    hipFree(d_part);
+    MCX_HIP(h, e1);
+    MCX_HIP(h, e2);
     return 0;
 }
 

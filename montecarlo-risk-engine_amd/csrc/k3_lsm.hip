@@ -211,6 +211,65 @@ __global__ __launch_bounds__(MCX_BLOCK) void k3_step_mfma(const K3Args a)
     }
 }
 
+// ---- product-batched step (books of thousands of products) --------------------------------------------
+// One launch runs the LSM step of MANY products at once: blockIdx.y = job, every job carries its own roll window, atoms,
+// shift/scale and cashflow-cache block.  The per-(product, date) launch + host round trip of mcx_lsm_step (~40 us each,
+// 800 k of them for the reference's 5,000-product book) becomes one launch per backward step of the whole book.
+struct K3Job {
+    int32_t ev_off, roll_begin, roll_end, pad;
+    int64_t w_off;                          // offset (doubles) of this product's [S][ld_w] cashflow cache in W
+    double shift, scale;
+    DevAtom num, x;
+};
+
+template <int K, int S>
+__global__ __launch_bounds__(MCX_BLOCK) void k3_step_batch(K3Args a, const K3Job* __restrict__ jobs, int blocks_per_job)
+{
+    constexpr int NM = (2 * K - 1) + S * K;
+    const K3Job jb = ldk_struct(&jobs[blockIdx.y]);
+    a.events += jb.ev_off; a.roll_begin = jb.roll_begin; a.roll_end = jb.roll_end; a.W += jb.w_off;
+    a.shift = jb.shift; a.scale = jb.scale; a.num = jb.num; a.x = jb.x;
+    double acc[NM];
+#pragma unroll
+    for (int q = 0; q < NM; ++q) acc[q] = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * MCX_BLOCK + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * MCX_BLOCK) {
+        double y[S], z;
+        k3_roll<S>(a, i, y, z);
+        double zp = 1.0;
+#pragma unroll
+        for (int k = 0; k < 2 * K - 1; ++k) {
+            acc[k] += zp;
+            if (k < K) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) acc[(2 * K - 1) + s * K + k] = fma(zp, y[s], acc[(2 * K - 1) + s * K + k]);
+            }
+            zp *= z;
+        }
+    }
+    __shared__ double lds[4];
+#pragma unroll
+    for (int q = 0; q < NM; ++q) {
+        const double r = block_sum(acc[q], lds);
+        if (threadIdx.x == 0) a.partials[((int64_t)blockIdx.y * blocks_per_job + blockIdx.x) * NM + q] = r;
+    }
+}
+
+// out[job][q] = sum over the job's blocks (fixed order: deterministic)
+__global__ void k3_finish_batch(const double* __restrict__ partials, int nm, int blocks_per_job, double* __restrict__ out, int ld_out)
+{
+    const int job = blockIdx.x, q = threadIdx.x;
+    if (q >= nm) return;
+    double s = 0.0;
+    for (int b = 0; b < blocks_per_job; ++b) s += partials[((int64_t)job * blocks_per_job + b) * nm + q];
+    out[(int64_t)job * ld_out + q] = s;
+}
+
+__global__ void k3_scatter_coeffs(const int64_t* __restrict__ offsets, const double* __restrict__ values, int len, double* __restrict__ coeffs)
+{
+    const int j = blockIdx.x;
+    for (int q = threadIdx.x; q < len; q += blockDim.x) coeffs[offsets[j] + q] = values[(int64_t)j * len + q];
+}
+
 __global__ void k3_finish(const double* __restrict__ partials, int nm, int n_blocks, double* __restrict__ out)
 {
     const int q = blockIdx.x;
@@ -273,6 +332,20 @@ int dispatch_k3(int K, const K3Args& a, int grid, bool mfma, hipStream_t s)
     case 4: launch_k3<4, S>(a, grid, mfma, s); return 0;
     case 5: launch_k3<5, S>(a, grid, mfma, s); return 0;
     case 6: launch_k3<6, S>(a, grid, mfma, s); return 0;
+    default: return -1;
+    }
+}
+
+template <int S>
+int dispatch_k3_batch(int K, const K3Args& a, const K3Job* jobs, dim3 grid, hipStream_t s)
+{
+    switch (K) {
+    case 1: hipLaunchKernelGGL((k3_step_batch<1, S>), grid, dim3(MCX_BLOCK), 0, s, a, jobs, (int)grid.x); return 0;
+    case 2: hipLaunchKernelGGL((k3_step_batch<2, S>), grid, dim3(MCX_BLOCK), 0, s, a, jobs, (int)grid.x); return 0;
+    case 3: hipLaunchKernelGGL((k3_step_batch<3, S>), grid, dim3(MCX_BLOCK), 0, s, a, jobs, (int)grid.x); return 0;
+    case 4: hipLaunchKernelGGL((k3_step_batch<4, S>), grid, dim3(MCX_BLOCK), 0, s, a, jobs, (int)grid.x); return 0;
+    case 5: hipLaunchKernelGGL((k3_step_batch<5, S>), grid, dim3(MCX_BLOCK), 0, s, a, jobs, (int)grid.x); return 0;
+    case 6: hipLaunchKernelGGL((k3_step_batch<6, S>), grid, dim3(MCX_BLOCK), 0, s, a, jobs, (int)grid.x); return 0;
     default: return -1;
     }
 }
@@ -344,5 +417,89 @@ extern "C" int mcx_lsm_step(mcx_handle* h, const mcx_book* b, int32_t product, i
     MCX_HIP(h, hipGetLastError());
     hipLaunchKernelGGL(k3_finish, dim3(NM), dim3(MCX_BLOCK), 0, s, h->d_ws, NM, grid, d_moments);
     MCX_HIP(h, hipGetLastError());
+    return 0;
+}
+
+extern "C" int mcx_lsm_step_batch(mcx_handle* h, const mcx_book* b, const mcx_lsm_job* h_jobs, int32_t n_jobs, int32_t n_states,
+                                  const double* d_paths, int64_t n_paths, int64_t ld, double* d_W, int64_t ld_w,
+                                  double* h_moments, int32_t flags, void* stream)
+{
+    if (!h || !b || !h_jobs || !d_paths || !d_W || !h_moments) return -1;
+    if (n_jobs <= 0) return 0;
+    const int K = b->n_basis, S = n_states;
+    if (S < 1 || S > MCX_MAX_STATES) MCX_FAIL(h, -2, "mcx_lsm_step_batch: n_states out of range");
+    const int NM = (2 * K - 1) + S * K;
+    if (ld < n_paths || ld_w < n_paths) MCX_FAIL(h, -2, "mcx_lsm_step_batch: leading dimension < n_paths");
+    hipStream_t s = (hipStream_t)stream;
+    if (n_paths <= 0) { memset(h_moments, 0, sizeof(double) * (size_t)n_jobs * NM); return 0; }
+    auto flat = [&](int id) { DevAtom o; const mcx_atom& q = b->h_atoms[id]; o.t_idx = q.t_idx; o.col = q.col; o.a = q.a; o.d = q.d; o.b = q.b; o.c0 = q.c0; o.c1 = q.c1; return o; };
+    std::vector<K3Job> jobs((size_t)n_jobs);
+    for (int j = 0; j < n_jobs; ++j) {
+        const mcx_lsm_job& q = h_jobs[j];
+        if (q.product < 0 || q.product >= b->n_products) MCX_FAIL(h, -2, "mcx_lsm_step_batch: job %d product out of range", j);
+        const DevProduct& pr = b->h_products[q.product];
+        if (pr.n_states != S) MCX_FAIL(h, -2, "mcx_lsm_step_batch: job %d has %d states, the batch %d", j, pr.n_states, S);
+        if (q.roll_begin < 0 || q.roll_end < q.roll_begin || q.roll_end > pr.cf_end - pr.cf_begin) MCX_FAIL(h, -2, "mcx_lsm_step_batch: job %d roll window", j);
+        if (q.num_atom < 0 || q.num_atom >= b->n_atoms || q.x_atom < 0 || q.x_atom >= b->n_atoms) MCX_FAIL(h, -2, "mcx_lsm_step_batch: job %d atoms", j);
+        if (q.w_offset < 0) MCX_FAIL(h, -2, "mcx_lsm_step_batch: job %d cache offset", j);
+        K3Job& o = jobs[j];
+        o.ev_off = pr.cf_begin; o.roll_begin = q.roll_begin; o.roll_end = q.roll_end; o.pad = 0; o.w_off = q.w_offset;
+        o.shift = q.shift; o.scale = q.scale; o.num = flat(q.num_atom); o.x = flat(q.x_atom);
+    }
+    // few paths per product are the norm for big books: one block per 256 paths, capped
+    int bpj = mcx_grid_for(n_paths, MCX_BLOCK, 64);
+    const int max_jobs = 32768;
+    K3Job* d_jobs = nullptr;
+    double *d_part = nullptr, *d_out = nullptr;
+    const int chunk = n_jobs < max_jobs ? n_jobs : max_jobs;
+    MCX_HIP(h, hipMalloc(&d_jobs, sizeof(K3Job) * (size_t)chunk));
+    MCX_HIP(h, hipMalloc(&d_part, sizeof(double) * (size_t)chunk * bpj * NM));
+    MCX_HIP(h, hipMalloc(&d_out, sizeof(double) * (size_t)chunk * NM));
+    K3Args a;
+    memset(&a, 0, sizeof(a));
+    a.terms = b->d_terms; a.events = b->d_events; a.atoms = b->d_atoms; a.coeffs = b->d_coeffs; a.paths = d_paths;
+    a.W = d_W; a.partials = d_part; a.n = n_paths; a.ld = ld; a.ld_w = ld_w; a.n_basis = K; a.n_state = b->n_state;
+    a.f32_cache = (flags & MCX_LSM_F32_CACHE) ? 1 : 0;
+    int rc = 0;
+    for (int j0 = 0; j0 < n_jobs && rc == 0; j0 += chunk) {
+        const int nj = n_jobs - j0 < chunk ? n_jobs - j0 : chunk;
+        if (hipMemcpyAsync(d_jobs, jobs.data() + j0, sizeof(K3Job) * (size_t)nj, hipMemcpyHostToDevice, s) != hipSuccess) { rc = -100; break; }
+        const dim3 grid(bpj, nj);
+        switch (S) {
+        case 1: rc = dispatch_k3_batch<1>(K, a, d_jobs, grid, s); break;
+        case 2: rc = dispatch_k3_batch<2>(K, a, d_jobs, grid, s); break;
+        case 3: rc = dispatch_k3_batch<3>(K, a, d_jobs, grid, s); break;
+        case 4: rc = dispatch_k3_batch<4>(K, a, d_jobs, grid, s); break;
+        default: rc = -1; break;
+        }
+        if (rc != 0) break;
+        hipLaunchKernelGGL(k3_finish_batch, dim3(nj), dim3(64), 0, s, d_part, NM, bpj, d_out, NM);
+        if (hipMemcpyAsync(h_moments + (size_t)j0 * NM, d_out, sizeof(double) * (size_t)nj * NM, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = -100; break; }
+        if (hipStreamSynchronize(s) != hipSuccess) { rc = -100; break; }
+    }
+    hipFree(d_jobs); hipFree(d_part); hipFree(d_out);
+    if (rc == -1) MCX_FAIL(h, -3, "mcx_lsm_step_batch: unsupported (basis=%d, states=%d)", K, S);
+    if (rc != 0) MCX_FAIL(h, -100, "mcx_lsm_step_batch: HIP error: %s", hipGetErrorString(hipGetLastError()));
+    return 0;
+}
+
+extern "C" int mcx_book_set_coeffs_batch(mcx_handle* h, mcx_book* b, const int64_t* h_offsets, int32_t n, int32_t len,
+                                         const double* h_values, void* stream)
+{
+    if (!h || !b || !h_offsets || !h_values) return -1;
+    if (n <= 0 || len <= 0) return 0;
+    for (int j = 0; j < n; ++j)
+        if (h_offsets[j] < 0 || h_offsets[j] + len > b->n_coeffs) MCX_FAIL(h, -2, "mcx_book_set_coeffs_batch: range %d out of bounds", j);
+    hipStream_t s = (hipStream_t)stream;
+    int64_t* d_off = nullptr;
+    double* d_val = nullptr;
+    MCX_HIP(h, hipMalloc(&d_off, sizeof(int64_t) * (size_t)n));
+    MCX_HIP(h, hipMalloc(&d_val, sizeof(double) * (size_t)n * len));
+    MCX_HIP(h, hipMemcpyAsync(d_off, h_offsets, sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, s));
+    MCX_HIP(h, hipMemcpyAsync(d_val, h_values, sizeof(double) * (size_t)n * len, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k3_scatter_coeffs, dim3(n), dim3(64), 0, s, d_off, d_val, len, b->d_coeffs);
+    MCX_HIP(h, hipGetLastError());
+    MCX_HIP(h, hipStreamSynchronize(s));
+    hipFree(d_off); hipFree(d_val);
     return 0;
 }

@@ -82,3 +82,9 @@ def ptr(a: np.ndarray | None) -> C.c_void_p:
         return C.c_void_p(0)
     assert a.flags["C_CONTIGUOUS"]
     return C.c_void_p(a.ctypes.data)
+
+
+# mcx_lsm_job (include/mcx.h)
+LSM_JOB_DTYPE = np.dtype([("product", np.int32), ("roll_begin", np.int32), ("roll_end", np.int32), ("num_atom", np.int32),
+                          ("x_atom", np.int32), ("reserved", np.int32), ("w_offset", np.int64), ("shift", np.float64),
+                          ("scale", np.float64)], align=True)

@@ -21,7 +21,7 @@ _EXPORTS = [
     "mcx_abi_version", "mcx_create", "mcx_destroy", "mcx_last_error", "mcx_device_info",
     "mcx_sim_create", "mcx_sim_destroy", "mcx_generate_paths",
     "mcx_book_create", "mcx_book_destroy", "mcx_book_set_coeffs", "mcx_eval_book", "mcx_resolve_atoms",
-    "mcx_lsm_stats", "mcx_lsm_step",
+    "mcx_lsm_stats", "mcx_lsm_step", "mcx_lsm_step_batch", "mcx_book_set_coeffs_batch",
     "mcx_tangent_european", "mcx_fused_create", "mcx_fused_destroy", "mcx_fused_num_records", "mcx_fused_run", "mcx_fused_eval_paths",
     "mcx_reduce_vector", "mcx_reduce_profiles", "mcx_reduce_cva", "mcx_unsecured", "mcx_select_hist",
 ]
@@ -224,6 +224,26 @@ class HipBackend:
             _vp(W.data_ptr()), C.c_int64(W.shape[1]), _vp(moments.data_ptr()), C.c_int32(int(flags)), self._stream()),
             "mcx_lsm_step")
         return moments
+
+    def lsm_step_batch(self, book, jobs: np.ndarray, n_states: int, paths: torch.Tensor, W: torch.Tensor, ld_w: int,
+                       flags: int = 0) -> np.ndarray:
+        """jobs: LSM_JOB_DTYPE array (same number of exercise states); W: the flat cashflow-cache tensor; -> moments [n_jobs][NM]"""
+        jobs = np.ascontiguousarray(jobs, dtype=_abi.LSM_JOB_DTYPE)
+        n = paths.shape[2]
+        K = book.plan.n_basis
+        out = np.zeros((len(jobs), (2 * K - 1) + n_states * K))
+        self._check(self.lib.mcx_lsm_step_batch(
+            self.h, book.ptr, _abi.ptr(jobs), C.c_int32(len(jobs)), C.c_int32(n_states), _vp(paths.data_ptr()), C.c_int64(n),
+            C.c_int64(n), _vp(W.data_ptr()), C.c_int64(ld_w), _abi.ptr(out), C.c_int32(int(flags)), self._stream()),
+            "mcx_lsm_step_batch")
+        return out
+
+    def book_set_coeffs_batch(self, book, offsets: np.ndarray, values: np.ndarray):
+        off = np.ascontiguousarray(offsets, dtype=np.int64)
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        assert v.ndim == 2 and v.shape[0] == len(off)
+        self._check(self.lib.mcx_book_set_coeffs_batch(self.h, book.ptr, _abi.ptr(off), C.c_int32(len(off)), C.c_int32(v.shape[1]),
+                                                       _abi.ptr(v), self._stream()), "mcx_book_set_coeffs_batch")
 
     # ---- K4 / K5 -------------------------------------------------------------------------------------------------
     def reduce_vector(self, x: torch.Tensor) -> np.ndarray:

@@ -28,7 +28,8 @@ from ..metrics.risk_metrics import PathwisePrimitive, RiskMetrics
 from ..models.model import Model
 from ..models.model_config import ModelConfig
 from ..parallel import Shard
-from ..plan import BookCompiler, BookPlan, FusedPlan, SimPlan, UnsecuredSpec, solve_normal_equations
+from ..plan import (BookCompiler, BookPlan, FusedPlan, SimPlan, UnsecuredSpec, solve_normal_equations,
+                    solve_normal_equations_batch)
 from ..products.netting_set import NettingSet
 from ..products.product import Product
 from ..request_interface.request_interface import RequestInterface
@@ -101,6 +102,7 @@ class SimulationController:
         # from it; "fused" = a single launch, nothing materialised; (None/unfusable: K1, K2, K4 as separate launches)
         self.main_plan = "semi"
         self.materialize = False     # also write paths / cashflows / exposures in the fused pass (inspection, tests)
+        self.batch_lsm = True        # product-batched LSM pre-simulation (one launch per backward step of the whole book)
         self._backend = backend
         for i, p in enumerate(products):
             p.product_id = i
@@ -214,6 +216,16 @@ class SimulationController:
             off += E * S * K
             self._reg_coeff_base.append(off)
             off += len(p.regression_timeline) * S * K
+        expo_atom_cache: dict = {}
+
+        def expo_atoms(asset):       # (numeraire, SPOT) atoms of every exposure date, once per asset
+            hit = expo_atom_cache.get(asset)
+            if hit is None:
+                hit = [(comp.atom(self.numeraire_requests[(t, "numeraire")], "numeraire", t),
+                        comp.atom(self.spot_requests[(t, asset)], asset, t)) for t in expo_times]
+                expo_atom_cache[asset] = hit
+            return hit
+
         for p_i, p in enumerate(self.products):
             S = p.get_num_states()
             skip = self._can_skip_monte_carlo_for_product(p)
@@ -242,8 +254,7 @@ class SimulationController:
                         while t_start < len(pdates) and pdates[t_start] <= t:            # controller.py:417-426
                             emit_cash(cash[t_start])
                             t_start += 1
-                        num = comp.atom(self.numeraire_requests[(t, "numeraire")], "numeraire", t)
-                        x = comp.atom(self.spot_requests[(t, p.asset_ids[0])], p.asset_ids[0], t)
+                        num, x = expo_atoms(p.asset_ids[0])[i]
                         if analytic:
                             aux = (self.model._pf(1), self.model._pf(2), float(p.exercise_date[0]) - t, 0.0)
                             comp.add_event(_abi.EV_EXPO_BS, comp.tidx(t), num, x, (0, 0), -1, i, p._K, p._sign(), aux)
@@ -275,24 +286,43 @@ class SimulationController:
 
     # ---- pre-simulation: Longstaff-Schwartz (controller.py:272-383) ----------------------------------------------
     def _regression_schedule(self, p_i: int, product: Product):
-        """backward list of (t_reg, roll_begin, roll_end, store_prod_idx|None, store_expo_idx|None)"""
-        pdates = [float(t) for t in product.product_timeline]
-        preg = [float(t) for t in product.regression_timeline]
+        """backward list of (t_reg, roll_begin, roll_end, store_prod_idx|None, store_expo_idx|None).  Memoised on the
+        product's timelines: books of thousands of products share a handful of distinct schedules."""
+        pdates = tuple(float(t) for t in product.product_timeline)
+        preg = tuple(float(t) for t in product.regression_timeline)
+        cache = self.__dict__.setdefault("_sched_cache", {})
+        hit = cache.get((pdates, preg))
+        if hit is not None:
+            return hit
         reg_tl = sorted(set(preg) | {float(t) for t in self.exposure_timeline})
         P = len(pdates)
         last = P
         sched = []
+        pd_arr = np.asarray(pdates)
+        reg_pos = {t: i for i, t in enumerate(preg)}
         for t_reg in reversed(reg_tl):
-            idx = int(np.searchsorted(np.asarray(pdates), t_reg, side="left"))
+            idx = int(np.searchsorted(pd_arr, t_reg, side="left"))
             if idx >= P:
                 continue
             t_next = idx + 1 if pdates[idx] == t_reg else idx
             roll = (t_next, last) if t_next < last else (last, last)
             if t_next < last:
                 last = t_next
-            sched.append((t_reg, roll[0], roll[1], preg.index(t_reg) if t_reg in preg else None,
-                          self._exposure_time_to_idx.get(t_reg)))
+            sched.append((t_reg, roll[0], roll[1], reg_pos.get(t_reg), self._exposure_time_to_idx.get(t_reg)))
+        cache[(pdates, preg)] = sched
         return sched
+
+    def _regression_atoms(self, sched, asset_id):
+        """(numeraire atom, explanatory SPOT atom) of every step of a schedule, memoised per (schedule, asset)"""
+        cache = self.__dict__.setdefault("_sched_atom_cache", {})
+        key = (id(sched), asset_id)
+        hit = cache.get(key)
+        if hit is None:
+            comp = self._comp
+            hit = [(comp.atom(AtomicRequest(AtomicRequestType.NUMERAIRE, t_reg), "numeraire", t_reg),
+                    comp.atom(AtomicRequest(AtomicRequestType.SPOT), asset_id, t_reg)) for (t_reg, *_r) in sched]
+            cache[key] = hit
+        return hit
 
     def _perform_regression(self, shard: Shard, sim_plan: SimPlan, sim):
         be = self.backend
@@ -311,12 +341,7 @@ class SimulationController:
             if not self._product_requires_regression(p) or p_i not in self._mc_products:
                 continue
             sched = self._regression_schedule(p_i, p)
-            atoms = []
-            for (t_reg, *_rest) in sched:
-                num = comp.atom(AtomicRequest(AtomicRequestType.NUMERAIRE, t_reg), "numeraire", t_reg)
-                x = comp.atom(AtomicRequest(AtomicRequestType.SPOT), p.asset_ids[0], t_reg)
-                atoms.append((num, x))
-            jobs.append((p_i, p, sched, atoms))
+            jobs.append((p_i, p, sched, self._regression_atoms(sched, p.asset_ids[0])))
         if len(self._comp.atoms) != len(self.book_plan.atoms):
             raise RuntimeError("internal: regression atoms must be registered before the book is frozen")
         # range of every explanatory variable (conditioning of the monomial basis; exact-degeneracy detection)
@@ -327,6 +352,10 @@ class SimulationController:
             lo, hi = g[:, :, 0].min(axis=0), g[:, :, 1].max(axis=0)
             x_range = {x: (lo[i], hi[i]) for i, x in enumerate(x_ids)}
         lsm_flags = (_abi.LSM_MFMA if self.use_mfma else 0) | (_abi.LSM_F32_CACHE if self.reference_float32_cf_cache else 0)
+        if not jobs:
+            return
+        if self.batch_lsm and not self.use_mfma:
+            return self._perform_regression_batched(shard, jobs, x_range, paths, n_local, K, lsm_flags)
         for p_i, p, sched, atoms in jobs:
             S = p.get_num_states()
             W = be.zeros(S, n_local)
@@ -345,13 +374,64 @@ class SimulationController:
                     self.regression_coeffs[p_i][expo_idx] = torch.from_numpy(coeffs)
                     be.book_set_coeffs(self.book, self._expo_coeff_base[p_i] + expo_idx * S * K, coeffs)
 
+    def _perform_regression_batched(self, shard: Shard, jobs, x_range, paths, n_local: int, K: int, lsm_flags: int):
+        """The backward LSM induction of ALL products at once: step r of every product's schedule runs in one launch per
+        exercise-state count (mcx_lsm_step_batch), the K x K systems are solved in one batched numpy call and the
+        coefficients go back in one scatter.  Same arithmetic per (product, date) as the per-product loop above
+        (reference: controller.py:289-383, one Python iteration per product and date)."""
+        be = self.backend
+        S_of = [p.get_num_states() for _, p, _, _ in jobs]
+        w_off, tot = [], 0
+        for S in S_of:
+            w_off.append(tot)
+            tot += S * n_local
+        W = be.zeros(max(tot, 1))
+        mirror = np.zeros(len(self.book_plan.coeffs))                 # host image of the coefficients this pass produces
+        max_len = max(len(sched) for _, _, sched, _ in jobs)
+        for r in range(max_len):
+            by_S: dict[int, list[int]] = {}
+            for j, (_, _, sched, _) in enumerate(jobs):
+                if r < len(sched):
+                    by_S.setdefault(S_of[j], []).append(j)
+            for S, members in sorted(by_S.items()):
+                arr = np.zeros(len(members), dtype=_abi.LSM_JOB_DTYPE)
+                xmin = np.zeros(len(members)); deg = np.zeros(len(members), dtype=bool)
+                targets = []                                          # (row in arr, coefficient offset)
+                for q, j in enumerate(members):
+                    p_i, p, sched, atoms = jobs[j]
+                    (t_reg, r0, r1, prod_idx, expo_idx), (num, x) = sched[r], atoms[r]
+                    lo, hi = x_range[x]
+                    degenerate = not (hi > lo)
+                    arr[q] = (p_i, r0, r1, num, x, 0, w_off[j], 0.5 * (lo + hi) if not degenerate else lo,
+                              2.0 / (hi - lo) if not degenerate else 1.0)
+                    xmin[q], deg[q] = lo, degenerate
+                    if prod_idx is not None:
+                        targets.append((q, self._reg_coeff_base[p_i] + prod_idx * S * K))
+                    if expo_idx is not None:
+                        targets.append((q, self._expo_coeff_base[p_i] + expo_idx * S * K))
+                mom = be.lsm_step_batch(self.book, arr, S, paths, W, n_local, flags=lsm_flags)
+                mom = shard.all_reduce_np(mom)
+                coeffs = solve_normal_equations_batch(mom, K, S, arr["shift"], arr["scale"], deg, xmin).reshape(len(members), S * K)
+                if targets:
+                    rows = np.array([t[0] for t in targets]); offs = np.array([t[1] for t in targets], dtype=np.int64)
+                    vals = coeffs[rows]
+                    be.book_set_coeffs_batch(self.book, offs, vals)
+                    mirror[offs[:, None] + np.arange(S * K)[None, :]] = vals
+        E = len(self.exposure_timeline)
+        for p_i, p, _, _ in jobs:
+            S = p.get_num_states()
+            b0 = self._expo_coeff_base[p_i]
+            self.regression_coeffs[p_i] = torch.from_numpy(mirror[b0:b0 + E * S * K].reshape(E, S, K).copy())
+            R = len(p.regression_timeline)
+            if R:
+                b1 = self._reg_coeff_base[p_i]
+                p.regression_coeffs = torch.from_numpy(mirror[b1:b1 + R * S * K].reshape(R, S, K).copy())
+
     def _register_regression_atoms(self):
         """atoms the LSM needs must exist before the book is uploaded"""
         for p_i, p in enumerate(self.products):
             if self._product_requires_regression(p) and p_i in self._mc_products:
-                for (t_reg, *_r) in self._regression_schedule(p_i, p):
-                    self._comp.atom(AtomicRequest(AtomicRequestType.NUMERAIRE, t_reg), "numeraire", t_reg)
-                    self._comp.atom(AtomicRequest(AtomicRequestType.SPOT), p.asset_ids[0], t_reg)
+                self._regression_atoms(self._regression_schedule(p_i, p), p.asset_ids[0])
 
     def perform_prepocessing(self, request_interface: RequestInterface):   # (sic) reference spelling
         request_interface.collect_and_index_requests(self.products, self.simulation_timeline, self._get_requests(),
@@ -475,11 +555,14 @@ class SimulationController:
         (the reference's perform_prepocessing, controller.py:257-292)"""
         be = self.backend
         self._shard = Shard()
+        t0 = time.perf_counter()
         self._compile_all()
+        t1 = time.perf_counter()
         self.sim_plan = SimPlan(self.model, self.simulation_timeline.numpy(), self.simulation_scheme, self.num_steps)
         self._sim = be.sim_create(self.sim_plan)
         if self.requires_regression:
             self._perform_regression(self._shard, self.sim_plan, self._sim)
+        self.prepare_timings = dict(compile=t1 - t0, presim_and_regression=time.perf_counter() - t1)
         off, n_local = self._shard.split(self.num_paths_mainsim)
         self._main_engine = MonteCarloEngine(self.simulation_timeline, self.simulation_scheme, self.model, n_local,
                                              self.num_steps, is_pre_simulation=False, path_offset=off, backend=be,

@@ -108,13 +108,14 @@ class BookCompiler:
         return self.time_to_index[float(time)]
 
     def atom(self, req, asset_id, time) -> int:
-        ti = self.tidx(time)
-        key = (ti, asset_id, req.key())
-        if key not in self._atom_key:
+        ti = self.time_to_index[float(time)]
+        key = (ti, asset_id, req.request_type.value, req.id, req.time1, req.time2)
+        hit = self._atom_key.get(key)
+        if hit is None:
             co = self.model._atom(req, asset_id)
-            self._atom_key[key] = len(self.atoms)
+            hit = self._atom_key[key] = len(self.atoms)
             self.atoms.append((ti, -1 if co.col is None else co.col, co.a, co.d, co.b, co.c0, co.c1))
-        return self._atom_key[key]
+        return hit
 
     def const_atom(self, value: float) -> int:
         key = ("const", float(value))
@@ -211,6 +212,34 @@ def solve_normal_equations(moments: np.ndarray, K: int, S: int, shift: float, sc
         for j in range(k + 1):
             T[j, k] = (scale ** k) * math.comb(k, j) * ((-shift) ** (k - j))
     return (T @ b).T
+
+
+def solve_normal_equations_batch(moments: np.ndarray, K: int, S: int, shift: np.ndarray, scale: np.ndarray,
+                                 degenerate: np.ndarray, x0: np.ndarray) -> np.ndarray:
+    """`solve_normal_equations` for many (product, date) systems at once: moments [n][NM] -> coefficients [n][S][K]."""
+    m = np.asarray(moments, dtype=np.float64)
+    n_jobs = m.shape[0]
+    out = np.zeros((n_jobs, S, K))
+    if n_jobs == 0:
+        return out
+    idx = np.arange(K)[:, None] + np.arange(K)[None, :]
+    G = m[:, idx]                                                              # [n][K][K]
+    rhs = m[:, (2 * K - 1):(2 * K - 1) + S * K].reshape(n_jobs, S, K).transpose(0, 2, 1)    # [n][K][S]
+    regular = (~np.asarray(degenerate, dtype=bool)) & (m[:, 0] > 0)
+    if regular.any():
+        r = np.nonzero(regular)[0]
+        try:
+            b = np.linalg.solve(G[r], rhs[r])
+        except np.linalg.LinAlgError:
+            b = np.stack([np.linalg.lstsq(G[q], rhs[q], rcond=None)[0] for q in r])
+        T = np.zeros((len(r), K, K))
+        for k in range(K):
+            for j in range(k + 1):
+                T[:, j, k] = (scale[r] ** k) * math.comb(k, j) * ((-shift[r]) ** (k - j))
+        out[r] = np.matmul(T, b).transpose(0, 2, 1)
+    for q in np.nonzero(np.asarray(degenerate, dtype=bool) & (m[:, 0] > 0))[0]:
+        out[q] = solve_normal_equations(m[q], K, S, float(shift[q]), float(scale[q]), True, float(x0[q]))
+    return out
 
 
 class FusedPlan:

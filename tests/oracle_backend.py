@@ -121,6 +121,21 @@ class OracleBackend:
                               C.c_int64(W.shape[1]), _p(mom), C.c_int32(flags))
         return mom
 
+    def lsm_step_batch(self, book, jobs, n_states, paths, W, ld_w, flags=0):
+        """checker composition of orc_lsm_step over the jobs of one batch (the product's mcx_lsm_step_batch is one launch)"""
+        n = paths.shape[2]
+        K, S = book.plan.n_basis, n_states
+        out = np.zeros((len(jobs), (2 * K - 1) + S * K))
+        for j, q in enumerate(jobs):
+            Wp = W[int(q["w_offset"]):int(q["w_offset"]) + S * ld_w].view(S, ld_w)
+            out[j] = self.lsm_step(book, int(q["product"]), int(q["roll_begin"]), int(q["roll_end"]), int(q["num_atom"]),
+                                   int(q["x_atom"]), float(q["shift"]), float(q["scale"]), paths, Wp, flags).numpy()
+        return out
+
+    def book_set_coeffs_batch(self, book, offsets, values):
+        for off, v in zip(offsets, values):
+            self.book_set_coeffs(book, int(off), v)
+
     def reduce_vector(self, x):
         out = np.zeros(1, dtype=self._abi.ACC_DTYPE)
         self.lib.orc_reduce_vector(_p(x), C.c_int64(x.shape[0]), _p(out))

@@ -121,7 +121,7 @@ def main():
         t2 = time.perf_counter()
         out = dict(products=len(products), counts=counts, paths=args.paths, exposure_points=args.exposure_points,
                    timeline_size=int(sc.simulation_timeline.numel()), construct_s=t1 - t0, run_s=t2 - t1,
-                   products_per_second=len(products) / (t2 - t1), timings=sc.timings,
+                   products_per_second=len(products) / (t2 - t1), timings=sc.timings, prepare=getattr(sc, 'prepare_timings', None),
                    cva=float(res.get_results(ns.get_name(), cva.get_name(), evaluation_idx=0)),
                    mc_error=float(res.get_mc_error(ns.get_name(), cva.get_name(), evaluation_idx=0)), backend=args.backend)
         print(json.dumps(out, default=float), flush=True)
