@@ -5,7 +5,7 @@
 10-day MPoR collateral, 80 exposure dates, 1000 + 1000 paths, one Euler step per date — WITHOUT the gas-storage products
 (out of scope).  Prints products/s like the reference script.
 
-    python tools/large_book.py [--scale 1.0] [--paths 1000] [--backend hip|oracle]"""
+    python tools/large_book.py [--scale 1.0] [--paths 1000]"""
 import argparse
 import json
 import os
@@ -90,16 +90,10 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="fraction of the reference script's 4,990 non-storage products")
     ap.add_argument("--paths", type=int, default=1000)
     ap.add_argument("--exposure-points", type=int, default=80)
-    ap.add_argument("--backend", default="hip", choices=["hip", "oracle"])
     ap.add_argument("--repeat", type=int, default=2)
     args = ap.parse_args()
-    if args.backend == "hip":
-        from mcx import _native
-        be = _native.HipBackend(0)
-    else:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from oracle_backend import OracleBackend
-        be = OracleBackend()
+    from mcx import _native
+    be = _native.HipBackend(0)
     ids = [f"asset_{k}" for k in range(4)]
     counts = [max(1, int(round(c * args.scale))) for c in (3940, 100, 100, 200, 400, 180, 70)]
     for rep in range(args.repeat):
@@ -117,13 +111,13 @@ def main():
                                   SimulationScheme.EULER, backend=be)
         t1 = time.perf_counter()
         res = sc.run_simulation()
-        be.synchronize() if hasattr(be, "synchronize") else None
+        be.synchronize()
         t2 = time.perf_counter()
         out = dict(products=len(products), counts=counts, paths=args.paths, exposure_points=args.exposure_points,
                    timeline_size=int(sc.simulation_timeline.numel()), construct_s=t1 - t0, run_s=t2 - t1,
                    products_per_second=len(products) / (t2 - t1), timings=sc.timings, prepare=getattr(sc, 'prepare_timings', None),
                    cva=float(res.get_results(ns.get_name(), cva.get_name(), evaluation_idx=0)),
-                   mc_error=float(res.get_mc_error(ns.get_name(), cva.get_name(), evaluation_idx=0)), backend=args.backend)
+                   mc_error=float(res.get_mc_error(ns.get_name(), cva.get_name(), evaluation_idx=0)))
         print(json.dumps(out, default=float), flush=True)
 
 
