@@ -301,6 +301,34 @@ int  mcx_tangent_european(mcx_handle* h, const mcx_sim* sim, const mcx_tangent_o
                           double* d_cfs, double* d_dcfs, int64_t ld_out, const double* d_inject_z, const double* d_inject_u,
                           void* stream);
 
+/* ---- forward-mode pass through the exposure path (csrc/kt_book.hip) -------------------------------------------------------
+ * d metric / d theta for MCX_TANGENT_NP model parameters per pass, replacing torch.autograd.grad through pre-simulation, lstsq
+ * and main simulation (controller.py:609-627, :370-383).  The caller supplies the derivative of every host-computed descriptor
+ * number next to the primal descriptor:
+ *   h_dslot [n_slots][MCX_SLOT_NPARAM][NP], h_dinit [n_state][NP], h_daux [n_steps][n_slots][MCX_AUX][NP]   (simulation)
+ *   d_datoms [n_atoms][5][NP] = d(a, d, b, c0, c1)                                                          (book, device)
+ * Tangent tensors carry the parameter index outermost: d_dpaths [NP][T][D][ld], d_cfs [1+NP][n_ns][ld] (index 0 = value),
+ * d_expo [1+NP][n_ns][n_rows][ld].  Scope: EULER; BS / Vasicek / CIR++ slots; stateless products with cashflow, plain option
+ * and polynomial-exposure events; otherwise MCX_E_NOT_FUSABLE (the caller falls back to bump-and-revalue). */
+#define MCX_TANGENT_NP 4
+int  mcx_tangent_paths(mcx_handle* h, const mcx_sim* sim, const double* h_dslot, const double* h_dinit, const double* h_daux,
+                       uint64_t seed, uint64_t path_offset, int64_t n_paths, double* d_paths, double* d_dpaths, int64_t ld,
+                       const double* d_inject_z, void* stream);
+/* dual normal equations of (product, regression date): Y = numeraire * sum of the product's cash events with index >=
+ * first_event; h_moments [1+NP][(2K-1)+K]: sums of z^k (k < 2K-1) then of z^k Y (k < K), z = (x - shift) * scale */
+int  mcx_tangent_lsm(mcx_handle* h, const mcx_book* book, int32_t product, int32_t first_event, int32_t num_atom, int32_t x_atom,
+                     double shift, double scale, const double* d_datoms, const double* d_paths, const double* d_dpaths,
+                     int64_t n_paths, int64_t ld, int32_t n_dates, double* h_moments, void* stream);
+int  mcx_tangent_eval(mcx_handle* h, const mcx_book* book, const double* d_datoms, const double* d_coeffs, const double* d_dcoeffs,
+                      const double* d_paths, const double* d_dpaths, int64_t n_paths, int64_t ld, int32_t n_dates,
+                      double* d_cfs, double* d_expo, void* stream);
+/* per-path CVA of one netting set with tangents: d_out [1+NP][ld]; d_expo_ns = the netting set's block of d_expo,
+ * expo_tangent_stride = doubles between consecutive tangent images (n_ns * n_rows * ld) */
+int  mcx_tangent_cva(mcx_handle* h, const mcx_book* book, const double* d_datoms, const int32_t* h_rows, const int32_t* h_surv,
+                     const int32_t* h_cond, int32_t n_dates_metric, double threshold, double recovery, const double* d_expo_ns,
+                     int64_t expo_tangent_stride, const double* d_paths, const double* d_dpaths, int64_t n_paths, int64_t ld,
+                     int32_t n_dates, double* d_out, void* stream);
+
 /* K3 — Longstaff-Schwartz normal equations (controller/controller.py:316-374).
  * mcx_lsm_stats: h_out[2*i+0] = min x_i, h_out[2*i+1] = max x_i over local paths for each explanatory atom (basis centring /
  *                scaling z = (x-shift)*scale, and detection of the exactly rank-1 regression at the calibration date).

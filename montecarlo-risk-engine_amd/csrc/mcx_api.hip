@@ -143,6 +143,10 @@ extern "C" int mcx_book_create(mcx_handle* h, const mcx_book_desc* d, mcx_book**
     b->h_terms = terms; b->h_terms.resize(d->n_terms);
     b->h_event_t_idx.resize(d->n_events);
     for (int i = 0; i < d->n_events; ++i) b->h_event_t_idx[i] = d->events[i].t_idx;
+    // atom ids behind the flattened copies (the tangent kernels index per-atom derivative rows, kt_book.hip)
+    b->h_event_num_atom.resize(d->n_events); b->h_event_x_atom.resize(d->n_events); b->h_term_atom.resize(d->n_terms);
+    for (int i = 0; i < d->n_events; ++i) { b->h_event_num_atom[i] = d->events[i].num_atom; b->h_event_x_atom[i] = d->events[i].x_atom; }
+    for (int i = 0; i < d->n_terms; ++i) b->h_term_atom[i] = d->terms[i].atom;
     b->expo_needs_memset = false;
     if (d->want_expo)
         for (size_t q = 0; q < (size_t)d->n_netting_sets * d->n_expo_rows; ++q)

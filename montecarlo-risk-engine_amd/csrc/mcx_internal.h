@@ -82,6 +82,7 @@ struct mcx_book {
     std::vector<DevEvent> h_events;
     std::vector<DevTerm> h_terms;
     std::vector<int32_t> h_event_t_idx;
+    std::vector<int32_t> h_event_num_atom, h_event_x_atom, h_term_atom;
     std::vector<DevProduct> h_products;
     std::vector<uint8_t> ns_has_writer;   // [n_netting_sets * n_expo_rows]
     bool expo_needs_memset;

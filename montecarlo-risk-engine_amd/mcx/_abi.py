@@ -88,3 +88,5 @@ def ptr(a: np.ndarray | None) -> C.c_void_p:
 LSM_JOB_DTYPE = np.dtype([("product", np.int32), ("roll_begin", np.int32), ("roll_end", np.int32), ("num_atom", np.int32),
                           ("x_atom", np.int32), ("reserved", np.int32), ("w_offset", np.int64), ("shift", np.float64),
                           ("scale", np.float64)], align=True)
+
+TANGENT_NP = 4          # MCX_TANGENT_NP: model parameters per forward-mode pass (csrc/kt_book.hip)

@@ -22,6 +22,7 @@ _EXPORTS = [
     "mcx_sim_create", "mcx_sim_destroy", "mcx_generate_paths",
     "mcx_book_create", "mcx_book_destroy", "mcx_book_set_coeffs", "mcx_eval_book", "mcx_resolve_atoms",
     "mcx_lsm_stats", "mcx_lsm_step", "mcx_lsm_step_batch", "mcx_book_set_coeffs_batch",
+    "mcx_tangent_paths", "mcx_tangent_lsm", "mcx_tangent_eval", "mcx_tangent_cva",
     "mcx_tangent_european", "mcx_fused_create", "mcx_fused_destroy", "mcx_fused_num_records", "mcx_fused_run", "mcx_fused_eval_paths",
     "mcx_reduce_vector", "mcx_reduce_profiles", "mcx_reduce_cva", "mcx_unsecured", "mcx_select_hist",
 ]
@@ -202,6 +203,59 @@ class HipBackend:
             C.c_int64(n_paths), C.c_int64(n_paths), dp(cfs), dp(dcfs), C.c_int64(n_paths), dp(inject_z), dp(inject_u),
             self._stream()), "mcx_tangent_european")
         return cfs, dcfs
+
+    # ---- forward-mode pass through the exposure path (csrc/kt_book.hip) ----------------------------------------------
+    def tangent_paths(self, sim, dslot: np.ndarray, dinit: np.ndarray, daux: np.ndarray, seed: int, path_offset: int,
+                      n_paths: int, inject_z=None):
+        plan = sim.plan
+        NP = _abi.TANGENT_NP
+        paths = self.empty(plan.n_dates, plan.n_state, n_paths)
+        dpaths = self.empty(NP, plan.n_dates, plan.n_state, n_paths)
+        a = [np.ascontiguousarray(x, dtype=np.float64) for x in (dslot, dinit, daux)]
+        assert a[0].shape == (plan.n_slots, _abi.SLOT_NPARAM, NP) and a[1].shape == (plan.n_state, NP)
+        assert a[2].shape == (plan.n_steps, plan.n_slots, _abi.AUX, NP)
+        self._check(self.lib.mcx_tangent_paths(
+            self.h, sim.ptr, _abi.ptr(a[0]), _abi.ptr(a[1]), _abi.ptr(a[2]), C.c_uint64(seed), C.c_uint64(path_offset),
+            C.c_int64(n_paths), _vp(paths.data_ptr()), _vp(dpaths.data_ptr()), C.c_int64(n_paths),
+            _vp(inject_z.data_ptr() if inject_z is not None else 0), self._stream()), "mcx_tangent_paths")
+        return paths, dpaths
+
+    def tangent_lsm(self, book, product: int, first_event: int, num_atom: int, x_atom: int, shift: float, scale: float,
+                    datoms: torch.Tensor, paths: torch.Tensor, dpaths: torch.Tensor) -> np.ndarray:
+        K = book.plan.n_basis
+        out = np.zeros((1 + _abi.TANGENT_NP, (2 * K - 1) + K))
+        n = paths.shape[2]
+        self._check(self.lib.mcx_tangent_lsm(
+            self.h, book.ptr, C.c_int32(product), C.c_int32(first_event), C.c_int32(num_atom), C.c_int32(x_atom),
+            C.c_double(shift), C.c_double(scale), _vp(datoms.data_ptr()), _vp(paths.data_ptr()), _vp(dpaths.data_ptr()),
+            C.c_int64(n), C.c_int64(n), C.c_int32(paths.shape[0]), _abi.ptr(out), self._stream()), "mcx_tangent_lsm")
+        return out
+
+    def tangent_eval(self, book, datoms: torch.Tensor, coeffs: torch.Tensor, dcoeffs: torch.Tensor, paths: torch.Tensor,
+                     dpaths: torch.Tensor):
+        plan = book.plan
+        n = paths.shape[2]
+        NP = _abi.TANGENT_NP
+        cfs = self.empty(1 + NP, plan.n_netting_sets, n)
+        expo = self.empty(1 + NP, plan.n_netting_sets, max(plan.n_expo_rows, 1), n)
+        self._check(self.lib.mcx_tangent_eval(
+            self.h, book.ptr, _vp(datoms.data_ptr()), _vp(coeffs.data_ptr()), _vp(dcoeffs.data_ptr()), _vp(paths.data_ptr()),
+            _vp(dpaths.data_ptr()), C.c_int64(n), C.c_int64(n), C.c_int32(paths.shape[0]), _vp(cfs.data_ptr()),
+            _vp(expo.data_ptr()), self._stream()), "mcx_tangent_eval")
+        return cfs, expo
+
+    def tangent_cva(self, book, datoms: torch.Tensor, rows, surv, cond, threshold: float, recovery: float, expo: torch.Tensor,
+                    ns_i: int, paths: torch.Tensor, dpaths: torch.Tensor) -> torch.Tensor:
+        n = paths.shape[2]
+        r, s, c = (np.ascontiguousarray(x, dtype=np.int32) for x in (rows, surv, cond))
+        out = self.empty(1 + _abi.TANGENT_NP, n)
+        stride = expo.shape[1] * expo.shape[2] * expo.shape[3]
+        self._check(self.lib.mcx_tangent_cva(
+            self.h, book.ptr, _vp(datoms.data_ptr()), _abi.ptr(r), _abi.ptr(s), _abi.ptr(c), C.c_int32(len(r)),
+            C.c_double(threshold), C.c_double(recovery), _vp(expo[0, ns_i].data_ptr()), C.c_int64(stride), _vp(paths.data_ptr()),
+            _vp(dpaths.data_ptr()), C.c_int64(n), C.c_int64(n), C.c_int32(paths.shape[0]), _vp(out.data_ptr()), self._stream()),
+            "mcx_tangent_cva")
+        return out
 
     # ---- K3 ------------------------------------------------------------------------------------------------------
     def lsm_stats(self, book, atom_ids, paths: torch.Tensor) -> np.ndarray:

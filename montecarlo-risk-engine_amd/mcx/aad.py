@@ -9,6 +9,9 @@ d PV / d theta_j = mean_j — identical to the reference's pathwise gradient, in
 Tangent kernels exist (BASELINE configs 2 and 4) for PV metrics of European options on an Equity under a single
 Black-Scholes or Heston model.
 
+Sensitivities through the LSM regression (CVA / PV of stateless books under BS / Vasicek / CIR++ Euler) run in forward mode too:
+`run_with_tangent_book` drives csrc/kt_book.hip (dual paths -> dual normal equations -> dual book -> dual CVA).
+
 Every other configuration (`run_with_bumps`): sensitivities through the LSM regression — CVA / EPE / PFE greeks, SURVEY §8f
 rank 1, reference test `tests/pytests/test_cva_large_netting_set_aad_vs_fd.py` — are computed by CENTRAL DIFFERENCES WITH
 COMMON RANDOM NUMBERS: the Philox counters (or the injected draws) are identical in the bumped runs, so the difference
@@ -163,3 +166,168 @@ def tangent_kernels_apply(sc) -> bool:
         return True
     except NotImplementedError:
         return False
+
+
+# ---- forward mode through the exposure path (csrc/kt_book.hip) ---------------------------------------------------------------
+class _NoTangentForm(Exception):
+    pass
+
+
+def _host_descriptors(sc):
+    """every host-computed number the kernels consume (slot parameters, initial state, per-step tables, atom coefficients) of a
+    controller, WITHOUT touching the GPU"""
+    from .plan import BookPlan
+    sc._compile()
+    if sc.requires_regression:
+        sc._register_regression_atoms()
+    book = BookPlan(sc._comp, *sc._plan_args)
+    sim = SimPlan(sc.model, sc.simulation_timeline.numpy(), sc.simulation_scheme, sc.num_steps)
+    slots = np.array([[sim.desc.slots[s].p[j] for j in range(_abi.SLOT_NPARAM)] for s in range(sim.n_slots)])
+    atoms = np.stack([book.atoms[k].astype(np.float64) for k in ("a", "d", "b", "c0", "c1")], axis=1) if len(book.atoms) else np.zeros((0, 5))
+    shape = (tuple(book.atoms["t_idx"]), tuple(book.atoms["col"]), len(book.terms), len(book.events), sim.n_steps)
+    return dict(slots=slots, init=sim.init_state.copy(), aux=sim.aux.copy(), atoms=atoms), shape
+
+
+def _solve_dual(mom: np.ndarray, K: int, shift: float, scale: float, degenerate: bool, n_par: int):
+    """coefficients and their tangents in the RAW monomial basis from the dual moments of mcx_tangent_lsm:
+    G c = r  =>  dc = G^-1 (dr - dG c)   (what autograd through torch.linalg.lstsq returns at full rank)"""
+    m, dm = mom[0], mom[1:1 + n_par]
+    n = m[0]
+    c, dc = np.zeros(K), np.zeros((n_par, K))
+    if n <= 0:
+        return c, dc
+    if degenerate:
+        # all paths share x = x0 (t = calibration date): minimum-norm solution c = v ybar / (v.v), v = [1, x0, .., x0^(K-1)];
+        # z = x - x0 is zero in value, its tangent is d x0
+        x0 = shift
+        ybar, dybar, dx0 = m[2 * K - 1] / n, dm[:, 2 * K - 1] / n, dm[:, 1] / n
+        v = np.array([x0 ** k for k in range(K)])
+        dv = np.array([k * x0 ** (k - 1) if k > 0 else 0.0 for k in range(K)])
+        vv = float(v @ v)
+        c = v * (ybar / vv)
+        for q in range(n_par):
+            dvq = dv * dx0[q]
+            dc[q] = dvq * (ybar / vv) + v * (dybar[q] / vv) - v * (ybar * 2.0 * float(v @ dvq) / vv ** 2)
+        return c, dc
+    idx = np.arange(K)[:, None] + np.arange(K)[None, :]
+    G, r = m[idx], m[2 * K - 1:2 * K - 1 + K]
+    cz = np.linalg.solve(G, r)
+    T = np.zeros((K, K))
+    for k in range(K):
+        for j in range(k + 1):
+            T[j, k] = (scale ** k) * math.comb(k, j) * ((-shift) ** (k - j))
+    c = T @ cz
+    for q in range(n_par):
+        dG, dr = dm[q][idx], dm[q][2 * K - 1:2 * K - 1 + K]
+        dc[q] = T @ np.linalg.solve(G, dr - dG @ cz)
+    return c, dc
+
+
+def run_with_tangent_book(sc):
+    """d PV / d theta and d CVA / d theta in forward mode through pre-simulation, regression and main simulation."""
+    import copy
+    from .parallel import Shard
+    from .request_interface.request_types import AtomicRequest, AtomicRequestType
+    if sc.requires_higher_order_derivatives:
+        raise _NoTangentForm("second order")
+    rm = sc.risk_metrics
+    if sc.simulation_scheme.name != "EULER" or any(ns.is_collateralized() for ns in sc.netting_sets):
+        raise _NoTangentForm("scheme / collateral")
+    if any(m.metric_type not in (MetricType.PV, MetricType.CVA) or not m._native for m in rm.metrics):
+        raise _NoTangentForm("metric")
+    if any(p.get_num_states() != 1 for p in sc.products) or len(sc.products) > 64:
+        raise _NoTangentForm("products")
+    if any(sc._can_skip_monte_carlo_for_product(p) or
+           (rm.requires_exposure_profiles() and sc._can_use_analytic_exposure_for_product(p)) for p in sc.products):
+        raise _NoTangentForm("analytic shortcuts")
+    t0 = time.perf_counter()
+    be, shard = sc.backend, Shard()
+    NP = _abi.TANGENT_NP
+    base = _clone_controller(sc, sc.model, sc.reference_float32_cf_cache)
+    res0 = base.run_simulation()
+    if base.book_plan.n_basis > 4:
+        raise _NoTangentForm("basis")
+    theta = [float(p.detach()) for p in sc.model.get_model_params()]
+    P = len(theta)
+    smoothing = getattr(sc.model, "perform_smoothing", False)
+
+    def bumped(j, value):
+        m = copy.deepcopy(sc.model)
+        m.perform_smoothing = smoothing
+        _set_param(m, j, value)
+        return _clone_controller(sc, m, False)
+
+    # derivative of every descriptor number (closed forms evaluated in float64 on the host): 4-point central differences with
+    # a wide step — truncation O(h^4) ~ 1e-12, rounding eps/h ~ 1e-13 relative.  (CIR++ sensitivities are small residuals of
+    # large cancelling terms: a 2-point formula with h = 1e-6 left 1e-5 relative noise on d CVA / d sigma_cir.)
+    d0, shape0 = _host_descriptors(_clone_controller(sc, copy.deepcopy(sc.model), False))
+    dd = {k: np.zeros(v.shape + (P,)) for k, v in d0.items()}
+    for j in range(P):
+        h = 1e-3 * max(abs(theta[j]), 1e-2)
+        ev = {}
+        for mult in (1, -1, 2, -2):
+            ev[mult], shp = _host_descriptors(bumped(j, theta[j] + mult * h))
+            if shp != shape0:
+                raise _NoTangentForm("descriptor structure depends on the parameters")
+        for k in dd:
+            dd[k][..., j] = (8.0 * (ev[1][k] - ev[-1][k]) - (ev[2][k] - ev[-2][k])) / (12.0 * h)
+    book, sim, K = base.book, base._sim, base.book_plan.n_basis
+    n_coeffs = len(base.book_plan.coeffs)
+    n_ns, n_metrics = len(sc.netting_sets), len(rm.metrics)
+    grads = [[[0.0] * P for _ in range(n_metrics)] for _ in range(n_ns)]
+    jobs = [(p_i, p) for p_i, p in enumerate(sc.products) if base._product_requires_regression(p) and p_i in base._mc_products]
+    rows = base.metric_exposure_indices.numpy().astype(np.int32) if rm.requires_exposure_profiles() else np.zeros(0, dtype=np.int32)
+
+    def mean_of(vec):
+        return mean_and_error(shard.all_gather_np(be.reduce_vector(vec).view(np.float64)))[0]
+
+    for c0 in range(0, P, NP):
+        sel = list(range(c0, min(c0 + NP, P)))
+        pad = lambda a: np.ascontiguousarray(np.concatenate([a[..., sel], np.zeros(a.shape[:-1] + (NP - len(sel),))], axis=-1))
+        dslot, dinit, daux = pad(dd["slots"]), pad(dd["init"]), pad(dd["aux"])
+        datoms = be.from_numpy(pad(dd["atoms"]))
+        coeffs, dcoeffs = np.zeros(max(n_coeffs, 1)), np.zeros((max(n_coeffs, 1), NP))
+        if jobs:
+            off, n_pre = shard.split(sc.num_paths_presim)
+            paths_pre, dpaths_pre = be.tangent_paths(sim, dslot, dinit, daux, 42 + sc.seed_offset, off, n_pre,
+                                                     sc._inject.get("pre", (None, None))[0])
+            plan = [(p_i, p, base._regression_schedule(p_i, p)) for p_i, p in jobs]
+            plan = [(p_i, p, sched, base._regression_atoms(sched, p.asset_ids[0])) for p_i, p, sched in plan]
+            x_ids = sorted({x for _, _, _, atoms in plan for _, x in atoms})
+            g = shard.all_gather_np(be.lsm_stats(book, x_ids, paths_pre))
+            lo, hi = g[:, :, 0].min(axis=0), g[:, :, 1].max(axis=0)
+            x_range = {x: (lo[i], hi[i]) for i, x in enumerate(x_ids)}
+            for p_i, p, sched, atoms in plan:
+                pdates = np.asarray([float(t) for t in p.product_timeline])
+                for (t_reg, _r0, _r1, _prod_idx, expo_idx), (num, x) in zip(sched, atoms):
+                    if expo_idx is None:
+                        continue
+                    xmin, xmax = x_range[x]
+                    degenerate = not (xmax > xmin)
+                    shift = 0.5 * (xmin + xmax) if not degenerate else xmin
+                    scale = 2.0 / (xmax - xmin) if not degenerate else 1.0
+                    first = int(np.searchsorted(pdates, t_reg, side="right"))      # cashflows strictly after t_reg (controller.py:323)
+                    mom = shard.all_reduce_np(be.tangent_lsm(book, p_i, first, num, x, shift, scale, datoms, paths_pre, dpaths_pre))
+                    c, dc = _solve_dual(mom, K, shift, scale, degenerate, NP)
+                    o = base._expo_coeff_base[p_i] + expo_idx * K
+                    coeffs[o:o + K], dcoeffs[o:o + K] = c, dc.T
+            del paths_pre, dpaths_pre
+        off, n_main = shard.split(sc.num_paths_mainsim)
+        paths, dpaths = be.tangent_paths(sim, dslot, dinit, daux, 43 + sc.seed_offset, off, n_main,
+                                         sc._inject.get("main", (None, None))[0])
+        cfs, expo = be.tangent_eval(book, datoms, be.from_numpy(coeffs), be.from_numpy(dcoeffs), paths, dpaths)
+        for ns_i, ns in enumerate(sc.netting_sets):
+            for m_i, m in enumerate(rm.metrics):
+                if m.metric_type == MetricType.PV:
+                    for q, j in enumerate(sel):
+                        grads[ns_i][m_i][j] = mean_of(cfs[1 + q, ns_i])
+                elif not (ns.counterparty_id is not None and m.counterparty_id != ns.counterparty_id):
+                    surv, cond = base._cva_atoms[m_i]
+                    out = be.tangent_cva(book, datoms, rows, surv, cond, ns.threshold, m.recovery_rate, expo, ns_i, paths, dpaths)
+                    for q, j in enumerate(sel):
+                        grads[ns_i][m_i][j] = mean_of(out[1 + q])
+        del paths, dpaths, cfs, expo
+    sc.sim_plan, sc.last_state = base.sim_plan, base.last_state
+    sc.timings = dict(total=time.perf_counter() - t0, tangent=True, forward_mode_passes=(P + NP - 1) // NP)
+    g = [[[tuple(grads[ns_i][m_i])] for m_i in range(n_metrics)] for ns_i in range(n_ns)]
+    return sc._package([[[tuple(v) for v in evals] for evals in per_metric] for per_metric in res0.results], g, [])

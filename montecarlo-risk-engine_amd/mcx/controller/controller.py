@@ -103,6 +103,7 @@ class SimulationController:
         self.main_plan = "semi"
         self.materialize = False     # also write paths / cashflows / exposures in the fused pass (inspection, tests)
         self.batch_lsm = True        # product-batched LSM pre-simulation (one launch per backward step of the whole book)
+        self.forward_mode = True     # differentiate=True: dual-number pass where it exists, bump-and-revalue otherwise
         self._backend = backend
         for i, p in enumerate(products):
             p.product_id = i
@@ -651,8 +652,18 @@ class SimulationController:
 
     def run_simulation(self) -> SimulationResults:
         if self.differentiate:
-            from ..aad import run_with_bumps, run_with_tangents, tangent_kernels_apply
-            return run_with_tangents(self) if tangent_kernels_apply(self) else run_with_bumps(self)
+            from ..aad import _NoTangentForm, run_with_bumps, run_with_tangent_book, run_with_tangents, tangent_kernels_apply
+            if tangent_kernels_apply(self):
+                return run_with_tangents(self)
+            if self.forward_mode and hasattr(self.backend, "tangent_paths"):
+                try:
+                    return run_with_tangent_book(self)          # forward mode through paths, regression, book and CVA
+                except _NoTangentForm:
+                    pass
+                except RuntimeError as e:                       # MCX_E_NOT_FUSABLE from the library: no tangent form
+                    if "(-10)" not in str(e):
+                        raise
+            return run_with_bumps(self)
         t0 = time.perf_counter()
         be = self.backend
         self.prepare()

@@ -255,3 +255,26 @@ def test_large_book_product_batched_kernels_match_oracle(hip, oracle):
     assert np.allclose(out["hip"][0], out["oracle"][0], rtol=1e-9, atol=1e-12), (out["hip"][0], out["oracle"][0])
     assert np.allclose(out["hip"][1], out["oracle"][1], rtol=1e-9, atol=1e-10)
     assert np.allclose(out["hip"][2], out["oracle"][2], rtol=1e-9, atol=1e-9)
+
+
+def test_forward_mode_cva_against_reference_autograd_and_bumps(hip):
+    """d CVA / d theta in dual numbers through pre-simulation, regression, book and CVA (csrc/kt_book.hip): vs the reference's
+    torch.autograd gradients on its recorded draws, and vs common-random-number bumps in Philox mode (PV + CVA)"""
+    from test_oracle_golden import check_lsm_sensitivities
+    sc, g = cases.make_controller("irs_cva_aad", hip)
+    res = sc.run_simulation()
+    assert sc.timings.get("tangent") is True and sc.timings.get("forward_mode_passes") == 2, sc.timings
+    check_lsm_sensitivities(sc, g, res)
+    out = {}
+    for fwd in (True, False):
+        ns, model, _ = cases.irs_cva()
+        rm = cases.RiskMetrics([cases.CVAMetric("cp", 0.4), cases.PVMetric()], exposure_timeline=np.arange(11) * 0.25)
+        sc = cases.SimulationController(ns, model, rm, 8192, 4096, 3, cases.E, differentiate=True, backend=hip)
+        sc.forward_mode = fwd
+        r = sc.run_simulation()
+        assert bool(sc.timings.get("tangent")) == fwd
+        out[fwd] = (np.array(r.derivatives[0][0][0]), np.array(r.derivatives[0][1][0]), np.array(r.results[0][0]))
+    for k in (0, 1):
+        scale = np.abs(out[False][k]).max()
+        assert np.allclose(out[True][k], out[False][k], rtol=2e-5, atol=2e-6 * scale), (k, out[True][k], out[False][k])
+    assert np.allclose(out[True][2], out[False][2], rtol=1e-12)
