@@ -355,7 +355,7 @@ class SimulationController:
         lsm_flags = (_abi.LSM_MFMA if self.use_mfma else 0) | (_abi.LSM_F32_CACHE if self.reference_float32_cf_cache else 0)
         if not jobs:
             return
-        if self.batch_lsm and not self.use_mfma:
+        if self.batch_lsm and not self.use_mfma and len(jobs) >= 4:       # (one or two products: the per-product loop has less fixed cost per step)
             return self._perform_regression_batched(shard, jobs, x_range, paths, n_local, K, lsm_flags)
         for p_i, p, sched, atoms in jobs:
             S = p.get_num_states()

@@ -58,6 +58,21 @@ def config3(be):
     return dict(config=3, seconds_total=dt, timings=sc.timings, cva=res.results[0][0][0])
 
 
+def config3_aad(be):
+    """config 3 with differentiate=True: d CVA / d(8 Vasicek + CIR++ parameters), forward mode (csrc/kt_book.hip) and the
+    common-random-number bump path beside it"""
+    out = dict(config="3 + sensitivities")
+    for fwd in (True, False):
+        sc = bench.build_controller(1 << 20, 131072, be)
+        sc.differentiate = True
+        sc.forward_mode = fwd
+        res, dt = timed(sc)
+        res, dt = timed(sc)
+        out["forward_mode" if fwd else "bumps"] = dict(seconds=dt, timings=sc.timings, cva=res.results[0][0][0],
+                                                       dcva=res.get_derivatives(0, 0, evaluation_idx=0))
+    return out
+
+
 def config4(be):
     model = HestonModel(0, 800.0, 0.04, 0.45545583, -0.78975708, 0.01713417, 2.0, 0.0286834)
     prod = EuropeanOption(Equity(), 1.0, 720.0, OptionType.CALL)
@@ -93,7 +108,7 @@ def config5(be):
 
 if __name__ == "__main__":
     be = _native.HipBackend(0)
-    which = [int(a) for a in sys.argv[1:]] or [2, 3, 4, 5]
+    which = [int(a) for a in sys.argv[1:]] or [2, 3, 4, 5, 6]
     for c in which:
-        r = {2: config2, 3: config3, 4: config4, 5: config5}[c](be)
+        r = {2: config2, 3: config3, 4: config4, 5: config5, 6: config3_aad}[c](be)
         print(json.dumps(r, default=float), flush=True)
