@@ -180,12 +180,14 @@ struct KTEventIds { int32_t num, x; };
 __device__ __forceinline__ DN kt_cash_event(const KTBook& b, const DevEvent& e, const KTEventIds& id, const int32_t* __restrict__ term_atom, int64_t i)
 {
     const DN num = kt_atom(b, e.num, id.num, i);
-    DN val = dconst<NP>(0.0);
+    DN val = dconst<NP>(0.0), own = dconst<NP>(0.0);
     for (int j = e.term_begin; j < e.term_end; ++j) {
         const DevTerm tm = ldk_struct(&b.terms[j]);
-        val = val + kt_atom(b, tm.atom, ldk(term_atom + j), i) * tm.w;
+        const DN v = kt_atom(b, tm.atom, ldk(term_atom + j), i) * tm.w;
+        if (tm.den < 0) val = val + v;
+        else own = own + v / kt_atom(b, ldk_struct(&b.atoms[tm.den]), tm.den, i);      // the unequal-tenor swap quirk (mcx_term.den)
     }
-    if (e.kind == MCX_EV_CASHFLOW) return val / num;
+    if (e.kind == MCX_EV_CASHFLOW) return val / num + own;
     const DN x = (val - e.strike) * e.sign;                         // torch.maximum(x, 0): gradient 1 for x > 0, 1/2 at the tie
     const double w = x.v > 0.0 ? 1.0 : (x.v == 0.0 ? 0.5 : 0.0);
     DN pay;
@@ -346,6 +348,41 @@ __global__ __launch_bounds__(MCX_BLOCK) void kt_cva(const KTCArgs a)
     for (int q = 0; q < NP; ++q) a.out[(1 + q) * a.b.ld + i] = cva.d[q] * a.lgd;
 }
 
+// ---- EPE / ENE profile tangents: sum_i 1[u > 0] du and sum_i 1[u < 0] du per metric date (epe_metric.py, ene_metric.py) -----
+struct KTFArgs {
+    const double* __restrict__ expo;           // [1+NP][n_rows][ld] of one netting set
+    const int32_t* __restrict__ rows;
+    double* __restrict__ partials;             // [n_dates][gridDim.x][2*NP]
+    int64_t ex_stride, n, ld;
+    double threshold;
+};
+
+__global__ __launch_bounds__(MCX_BLOCK) void kt_profiles(const KTFArgs a)
+{
+    const int m = blockIdx.y;
+    const int64_t row_off = (int64_t)ldk(a.rows + m) * a.ld;
+    double acc[2 * NP];
+#pragma unroll
+    for (int q = 0; q < 2 * NP; ++q) acc[q] = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * MCX_BLOCK + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * MCX_BLOCK) {
+        const double e = a.expo[row_off + i], h = a.threshold;
+        const double u = h == 0.0 ? e : (e > h ? e - h : (e < -h ? e + h : 0.0));
+        const double wp = u > 0.0 ? 1.0 : 0.0, wn = u < 0.0 ? 1.0 : 0.0;      // torch.relu: zero gradient at 0
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const double du = a.expo[(1 + q) * a.ex_stride + row_off + i];
+            acc[q] = fma(wp, du, acc[q]);
+            acc[NP + q] = fma(wn, du, acc[NP + q]);
+        }
+    }
+    __shared__ double lds[4];
+#pragma unroll
+    for (int q = 0; q < 2 * NP; ++q) {
+        const double r = block_sum(acc[q], lds);
+        if (threadIdx.x == 0) a.partials[((int64_t)m * gridDim.x + blockIdx.x) * 2 * NP + q] = r;
+    }
+}
+
 template <int NSLOT, int NZ>
 void launch_ktp(const KTPArgs& a, int grid, bool inject, hipStream_t s)
 {
@@ -490,8 +527,9 @@ extern "C" int mcx_tangent_eval(mcx_handle* h, const mcx_book* b, const double* 
             const DevEvent& e = b->h_events[q];
             const bool ok = e.kind == MCX_EV_CASHFLOW || (e.kind == MCX_EV_OPTION && e.aux[0] == 0.0) || e.kind == MCX_EV_EXPO_POLY;
             if (!ok) MCX_FAIL(h, MCX_E_NOT_FUSABLE, "mcx_tangent_eval: event %d (kind %d) has no tangent form", q, e.kind);
-            for (int j = e.term_begin; j < e.term_end; ++j)
-                if (b->h_terms[j].den >= 0) MCX_FAIL(h, MCX_E_NOT_FUSABLE, "mcx_tangent_eval: per-term denominators have no tangent form");
+            if (e.kind == MCX_EV_OPTION)
+                for (int j = e.term_begin; j < e.term_end; ++j)
+                    if (b->h_terms[j].den >= 0) MCX_FAIL(h, MCX_E_NOT_FUSABLE, "mcx_tangent_eval: option over per-term denominators");
         }
     }
     hipStream_t s = (hipStream_t)stream;
@@ -534,5 +572,31 @@ extern "C" int mcx_tangent_cva(mcx_handle* h, const mcx_book* b, const double* d
     hipLaunchKernelGGL(kt_cva, dim3((unsigned)((n_paths + MCX_BLOCK - 1) / MCX_BLOCK)), dim3(MCX_BLOCK), 0, s, a);
     MCX_HIP(h, hipGetLastError());
     MCX_HIP(h, hipStreamSynchronize(s));
+    return 0;
+}
+
+extern "C" int mcx_tangent_profiles(mcx_handle* h, const int32_t* h_rows, int32_t n_dates_metric, double threshold, const double* d_expo_ns,
+                                    int64_t expo_tangent_stride, int64_t n_paths, int64_t ld, double* h_out, void* stream)
+{
+    if (!h || !h_rows || !d_expo_ns || !h_out) return -1;
+    if (n_dates_metric <= 0) return 0;
+    memset(h_out, 0, sizeof(double) * (size_t)n_dates_metric * 2 * NP);
+    if (n_paths <= 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = mcx_grid_for(n_paths, MCX_BLOCK, 64);
+    std::vector<double> part((size_t)n_dates_metric * grid * 2 * NP);
+    DevBuf rows, d_part;
+    MCX_HIP(h, rows.upload(h_rows, sizeof(int32_t) * (size_t)n_dates_metric, s));
+    MCX_HIP(h, hipMalloc(&d_part.p, sizeof(double) * part.size()));
+    KTFArgs a;
+    a.expo = d_expo_ns; a.rows = (const int32_t*)rows.p; a.partials = (double*)d_part.p; a.ex_stride = expo_tangent_stride;
+    a.n = n_paths; a.ld = ld; a.threshold = threshold;
+    hipLaunchKernelGGL(kt_profiles, dim3(grid, n_dates_metric), dim3(MCX_BLOCK), 0, s, a);
+    MCX_HIP(h, hipGetLastError());
+    MCX_HIP(h, hipMemcpyAsync(part.data(), d_part.p, sizeof(double) * part.size(), hipMemcpyDeviceToHost, s));
+    MCX_HIP(h, hipStreamSynchronize(s));
+    for (int m = 0; m < n_dates_metric; ++m)
+        for (int b = 0; b < grid; ++b)
+            for (int q = 0; q < 2 * NP; ++q) h_out[(size_t)m * 2 * NP + q] += part[((size_t)m * grid + b) * 2 * NP + q];
     return 0;
 }

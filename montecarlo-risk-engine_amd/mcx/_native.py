@@ -22,7 +22,7 @@ _EXPORTS = [
     "mcx_sim_create", "mcx_sim_destroy", "mcx_generate_paths",
     "mcx_book_create", "mcx_book_destroy", "mcx_book_set_coeffs", "mcx_eval_book", "mcx_resolve_atoms",
     "mcx_lsm_stats", "mcx_lsm_step", "mcx_lsm_step_batch", "mcx_book_set_coeffs_batch",
-    "mcx_tangent_paths", "mcx_tangent_lsm", "mcx_tangent_eval", "mcx_tangent_cva",
+    "mcx_tangent_paths", "mcx_tangent_lsm", "mcx_tangent_eval", "mcx_tangent_cva", "mcx_tangent_profiles",
     "mcx_tangent_european", "mcx_fused_create", "mcx_fused_destroy", "mcx_fused_num_records", "mcx_fused_run", "mcx_fused_eval_paths",
     "mcx_reduce_vector", "mcx_reduce_profiles", "mcx_reduce_cva", "mcx_unsecured", "mcx_select_hist",
 ]
@@ -255,6 +255,17 @@ class HipBackend:
             C.c_double(threshold), C.c_double(recovery), _vp(expo[0, ns_i].data_ptr()), C.c_int64(stride), _vp(paths.data_ptr()),
             _vp(dpaths.data_ptr()), C.c_int64(n), C.c_int64(n), C.c_int32(paths.shape[0]), _vp(out.data_ptr()), self._stream()),
             "mcx_tangent_cva")
+        return out
+
+    def tangent_profiles(self, rows, threshold: float, expo: torch.Tensor, ns_i: int) -> np.ndarray:
+        """-> [n_dates][2][NP] local sums of 1[u>0] du (EPE) and 1[u<0] du (ENE)"""
+        r = np.ascontiguousarray(rows, dtype=np.int32)
+        out = np.zeros((len(r), 2, _abi.TANGENT_NP))
+        n = expo.shape[3]
+        stride = expo.shape[1] * expo.shape[2] * expo.shape[3]
+        self._check(self.lib.mcx_tangent_profiles(self.h, _abi.ptr(r), C.c_int32(len(r)), C.c_double(threshold),
+                                                  _vp(expo[0, ns_i].data_ptr()), C.c_int64(stride), C.c_int64(n), C.c_int64(n),
+                                                  _abi.ptr(out), self._stream()), "mcx_tangent_profiles")
         return out
 
     # ---- K3 ------------------------------------------------------------------------------------------------------

@@ -233,7 +233,7 @@ def run_with_tangent_book(sc):
     rm = sc.risk_metrics
     if sc.simulation_scheme.name != "EULER" or any(ns.is_collateralized() for ns in sc.netting_sets):
         raise _NoTangentForm("scheme / collateral")
-    if any(m.metric_type not in (MetricType.PV, MetricType.CVA) or not m._native for m in rm.metrics):
+    if any(m.metric_type not in (MetricType.PV, MetricType.CVA, MetricType.EPE, MetricType.ENE) or not m._native for m in rm.metrics):
         raise _NoTangentForm("metric")
     if any(p.get_num_states() != 1 for p in sc.products) or len(sc.products) > 64:
         raise _NoTangentForm("products")
@@ -274,7 +274,8 @@ def run_with_tangent_book(sc):
     book, sim, K = base.book, base._sim, base.book_plan.n_basis
     n_coeffs = len(base.book_plan.coeffs)
     n_ns, n_metrics = len(sc.netting_sets), len(rm.metrics)
-    grads = [[[0.0] * P for _ in range(n_metrics)] for _ in range(n_ns)]
+    n_eval = [len(res0.results[0][m_i]) for m_i in range(n_metrics)]
+    grads = [[[[0.0] * P for _ in range(n_eval[m_i])] for m_i in range(n_metrics)] for _ in range(n_ns)]     # [ns][metric][eval][param]
     jobs = [(p_i, p) for p_i, p in enumerate(sc.products) if base._product_requires_regression(p) and p_i in base._mc_products]
     rows = base.metric_exposure_indices.numpy().astype(np.int32) if rm.requires_exposure_profiles() else np.zeros(0, dtype=np.int32)
 
@@ -317,17 +318,25 @@ def run_with_tangent_book(sc):
                                          sc._inject.get("main", (None, None))[0])
         cfs, expo = be.tangent_eval(book, datoms, be.from_numpy(coeffs), be.from_numpy(dcoeffs), paths, dpaths)
         for ns_i, ns in enumerate(sc.netting_sets):
+            prof = None
             for m_i, m in enumerate(rm.metrics):
                 if m.metric_type == MetricType.PV:
                     for q, j in enumerate(sel):
-                        grads[ns_i][m_i][j] = mean_of(cfs[1 + q, ns_i])
+                        grads[ns_i][m_i][0][j] = mean_of(cfs[1 + q, ns_i])
+                elif m.metric_type in (MetricType.EPE, MetricType.ENE):
+                    if prof is None:            # [dates][2][NP] sums of 1[u>0] du / 1[u<0] du over all ranks
+                        prof = shard.all_reduce_np(be.tangent_profiles(rows, ns.threshold, expo, ns_i)) / float(sc.num_paths_mainsim)
+                    side = 0 if m.metric_type == MetricType.EPE else 1
+                    for e_i in range(n_eval[m_i]):
+                        for q, j in enumerate(sel):
+                            grads[ns_i][m_i][e_i][j] = float(prof[e_i, side, q])
                 elif not (ns.counterparty_id is not None and m.counterparty_id != ns.counterparty_id):
                     surv, cond = base._cva_atoms[m_i]
                     out = be.tangent_cva(book, datoms, rows, surv, cond, ns.threshold, m.recovery_rate, expo, ns_i, paths, dpaths)
                     for q, j in enumerate(sel):
-                        grads[ns_i][m_i][j] = mean_of(out[1 + q])
+                        grads[ns_i][m_i][0][j] = mean_of(out[1 + q])
         del paths, dpaths, cfs, expo
     sc.sim_plan, sc.last_state = base.sim_plan, base.last_state
     sc.timings = dict(total=time.perf_counter() - t0, tangent=True, forward_mode_passes=(P + NP - 1) // NP)
-    g = [[[tuple(grads[ns_i][m_i])] for m_i in range(n_metrics)] for ns_i in range(n_ns)]
+    g = [[[tuple(ev) for ev in grads[ns_i][m_i]] for m_i in range(n_metrics)] for ns_i in range(n_ns)]
     return sc._package([[[tuple(v) for v in evals] for evals in per_metric] for per_metric in res0.results], g, [])

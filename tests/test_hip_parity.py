@@ -265,6 +265,11 @@ def test_forward_mode_cva_against_reference_autograd_and_bumps(hip):
     res = sc.run_simulation()
     assert sc.timings.get("tangent") is True and sc.timings.get("forward_mode_passes") == 2, sc.timings
     check_lsm_sensitivities(sc, g, res)
+    # mixed BS + Vasicek + deterministic CIR++ book, CVA and every EPE date, the unequal-tenor swap's per-term denominators
+    sc, g = cases.make_controller("mixed_cva_aad", hip)
+    res = sc.run_simulation()
+    assert sc.timings.get("tangent") is True and sc.timings.get("forward_mode_passes") == 3, sc.timings
+    check_lsm_sensitivities(sc, g, res)
     out = {}
     for fwd in (True, False):
         ns, model, _ = cases.irs_cva()
