@@ -556,6 +556,7 @@ class SimulationController:
         (the reference's perform_prepocessing, controller.py:257-292)"""
         be = self.backend
         self._shard = Shard()
+        self.last_state = {}             # release the previous run's device buffers first: the allocator can reuse them
         t0 = time.perf_counter()
         self._compile_all()
         t1 = time.perf_counter()

@@ -26,7 +26,7 @@ def _worker(rank, world, port, name, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name", ["irs_cva", "bermudan_swaption", "netting"])
+@pytest.mark.parametrize("name", ["irs_cva", "bermudan_swaption", "netting", "mixed_book_multi"])   # last: product-batched LSM
 def test_two_ranks_match_single_process(name, oracle):
     single, _ = cases.make_controller(name, oracle, inject=False)
     ref = single.run_simulation().results
