@@ -51,6 +51,8 @@ def _check_supported(sc):
             raise NotImplementedError("differentiate=True: European options on an Equity underlying only")
     if sc.requires_higher_order_derivatives:
         raise NotImplementedError("second-order derivatives are not implemented")
+    if any(sc._can_skip_monte_carlo_for_product(p) for p in sc.products):
+        raise NotImplementedError("analytically valued products are not Monte-Carlo PVs")
     if len(sc.netting_sets) > _abi.FUSED_MAX_NS:
         raise NotImplementedError(f"differentiate=True: at most {_abi.FUSED_MAX_NS} netting sets")
 
@@ -340,3 +342,38 @@ def run_with_tangent_book(sc):
     sc.timings = dict(total=time.perf_counter() - t0, tangent=True, forward_mode_passes=(P + NP - 1) // NP)
     g = [[[tuple(ev) for ev in grads[ns_i][m_i]] for m_i in range(n_metrics)] for ns_i in range(n_ns)]
     return sc._package([[[tuple(v) for v in evals] for evals in per_metric] for per_metric in res0.results], g, [])
+
+
+# ---- analytically evaluated PV metrics: autograd on the closed form (host scalars, no simulation) --------------------------------
+def analytic_controller(sc) -> bool:
+    return bool(sc.products) and all(sc._can_skip_monte_carlo_for_product(p) and hasattr(p, "compute_pv_analytically_torch")
+                                     for p in sc.products)
+
+
+def run_analytic_with_autograd(sc):
+    """every product is valued by its closed form (PVMetric(ANALYTICAL)): first and, on request, second derivatives come from
+    torch.autograd on that closed form, as in the reference (controller.py:609-648; tests/pytests/test_european_option_hessian.py)"""
+    import torch
+    t0 = time.perf_counter()
+    theta = [torch.tensor(float(p.detach()), dtype=torch.float64, requires_grad=True) for p in sc.model.get_model_params()]
+    P = len(theta)
+    results, grads, hess = [], [], []
+    for ns_i, ns in enumerate(sc.netting_sets):
+        value = sum(p.compute_pv_analytically_torch(sc.model, theta) for p in ns.products)
+        g = torch.autograd.grad(value, theta, create_graph=sc.requires_higher_order_derivatives, allow_unused=True)
+        g = [torch.zeros((), dtype=torch.float64) if x is None else x for x in g]
+        row = tuple(float(x.detach()) for x in g)
+        H = None
+        if sc.requires_higher_order_derivatives:
+            H = []
+            for x in g:
+                if x.requires_grad:
+                    hx = torch.autograd.grad(x, theta, retain_graph=True, allow_unused=True)
+                    H.append(tuple(0.0 if y is None else float(y) for y in hx))
+                else:
+                    H.append(tuple(0.0 for _ in range(P)))
+        results.append([[(float(value.detach()), 0.0)] for _ in sc.risk_metrics.metrics])
+        grads.append([[row] for _ in sc.risk_metrics.metrics])
+        hess.append([[tuple(H)] if H is not None else [] for _ in sc.risk_metrics.metrics])
+    sc.timings = dict(total=time.perf_counter() - t0, analytic=True)
+    return sc._package(results, grads, hess if sc.requires_higher_order_derivatives else [])

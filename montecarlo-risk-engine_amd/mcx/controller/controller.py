@@ -653,7 +653,10 @@ class SimulationController:
 
     def run_simulation(self) -> SimulationResults:
         if self.differentiate:
-            from ..aad import _NoTangentForm, run_with_bumps, run_with_tangent_book, run_with_tangents, tangent_kernels_apply
+            from ..aad import (_NoTangentForm, analytic_controller, run_analytic_with_autograd, run_with_bumps,
+                               run_with_tangent_book, run_with_tangents, tangent_kernels_apply)
+            if analytic_controller(self):
+                return run_analytic_with_autograd(self)             # PVMetric(ANALYTICAL): autograd on the closed form
             if tangent_kernels_apply(self):
                 return run_with_tangents(self)
             if self.forward_mode and hasattr(self.backend, "tangent_paths"):

@@ -50,6 +50,34 @@ class EuropeanOption(Product):
     def compute_pv_analytically(self, model: BlackScholesModel):
         return torch.tensor([self._bs_price(model._pf(0), model._pf(2), model._pf(1), self._T)], dtype=FLOAT)
 
+    def compute_pv_analytically_torch(self, model, params):
+        """the same closed form on torch scalars (`params` in model.get_model_params() order): the analytic-evaluation path
+        differentiates it with torch.autograd exactly like the reference (controller.py:609-648, european_option.py:107-121)"""
+        spot, sigma, rate = params[0], params[1], params[2]
+        T, K = self._T, self._K
+        sq = math.sqrt(T)
+        d1 = (torch.log(spot / K) + (rate + 0.5 * sigma ** 2) * T) / (sigma * sq)
+        d2 = d1 - sigma * sq
+        cdf = lambda x: 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))
+        if self.option_type == OptionType.CALL:
+            return spot * cdf(d1) - K * torch.exp(-rate * T) * cdf(d2)
+        return K * torch.exp(-rate * T) * cdf(-d2) - spot * cdf(-d1)
+
+    def _d1(self, model):
+        spot, sigma, rate = model._pf(0), model._pf(1), model._pf(2)
+        return (math.log(spot / self._K) + (rate + 0.5 * sigma ** 2) * self._T) / (sigma * math.sqrt(self._T))
+
+    def compute_dVegadSigma_analytically(self, model: BlackScholesModel):           # vomma, european_option.py:290-304
+        d1 = self._d1(model)
+        d2 = d1 - model._pf(1) * math.sqrt(self._T)
+        pdf = math.exp(-0.5 * d1 * d1) / math.sqrt(2.0 * math.pi)
+        return torch.tensor([model._pf(0) * pdf * math.sqrt(self._T) * d1 * d2 / model._pf(1)], dtype=FLOAT)
+
+    def compute_dDeltadSpot_analytically(self, model: BlackScholesModel):           # gamma, european_option.py:306-320
+        d1 = self._d1(model)
+        pdf = math.exp(-0.5 * d1 * d1) / math.sqrt(2.0 * math.pi)
+        return torch.tensor([pdf / (model._pf(0) * model._pf(1) * math.sqrt(self._T))], dtype=FLOAT)
+
     def supports_analytic_pv(self, model) -> bool:
         return isinstance(model, BlackScholesModel)
 

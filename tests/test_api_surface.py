@@ -71,3 +71,31 @@ def test_analytic_pv_metric_skips_monte_carlo(oracle):
     res = sc.run_simulation()
     assert res.get_results("a", "pv", 0) == pytest.approx(31.96482, abs=1e-4)
     assert res.get_mc_error("a", "pv", 0) == 0.0
+
+
+def test_analytic_pv_first_and_second_derivatives(oracle):
+    """tests/pytests/test_european_option_hessian.py: PVMetric(ANALYTICAL) + differentiate + compute_higher_derivatives ->
+    autograd gradient and Hessian of the Black-Scholes closed form (no simulation)"""
+    import math
+    from mcx.metrics.metric import Metric
+    model = BlackScholesModel(0.0, 100.0, 0.05, 0.3)
+    product = EuropeanOption(Equity("id"), 2.0, 100.0, OptionType.CALL)
+    sc = SimulationController([NettingSet(name=product.get_name(), products=[product])], model,
+                              RiskMetrics(metrics=[PVMetric(evaluation_type=Metric.EvaluationType.ANALYTICAL)]), 1, 0, 1,
+                              SimulationScheme.ANALYTICAL, differentiate=True, backend=oracle)
+    sc.compute_higher_derivatives()
+    res = sc.run_simulation()
+    assert res.get_product_names() == ["EuropeanOption"] and res.get_metric_names() == ["pv"]
+    assert res.get_model_param_names() == ["spot", "volatility", "rate"]
+    S, K, r, sig, T = 100.0, 100.0, 0.05, 0.3, 2.0
+    d1 = (math.log(S / K) + (r + 0.5 * sig * sig) * T) / (sig * math.sqrt(T)); d2 = d1 - sig * math.sqrt(T)
+    N = lambda x: 0.5 * (1 + math.erf(x / math.sqrt(2))); phi = math.exp(-0.5 * d1 * d1) / math.sqrt(2 * math.pi)
+    assert res.get_results("EuropeanOption", "pv", evaluation_idx=0) == pytest.approx(S * N(d1) - K * math.exp(-r * T) * N(d2), rel=1e-12)
+    g = res.get_derivatives("EuropeanOption", "pv", evaluation_idx=0)
+    assert g["spot"] == pytest.approx(N(d1), rel=1e-10) and g["volatility"] == pytest.approx(S * phi * math.sqrt(T), rel=1e-10)
+    assert g["rate"] == pytest.approx(K * T * math.exp(-r * T) * N(d2), rel=1e-10)
+    H = res.get_second_derivatives("EuropeanOption", "pv", evaluation_idx=0)
+    assert float(H["spot"]["spot"]) == pytest.approx(float(product.compute_dDeltadSpot_analytically(model)), rel=1e-9)
+    assert float(H["volatility"]["volatility"]) == pytest.approx(float(product.compute_dVegadSigma_analytically(model)), rel=1e-9)
+    assert float(H["spot"]["volatility"]) == pytest.approx(float(H["volatility"]["spot"]), rel=1e-12)
+    assert float(H["spot"]["volatility"]) == pytest.approx(-phi * d2 / sig, rel=1e-9)          # vanna
