@@ -98,10 +98,15 @@ def _leaf_models(model):
 def _set_param(model, j: int, value: float):
     """overwrite the j-th entry of `model.get_model_params()` (ModelConfig: concatenation in sub-model order)"""
     import torch
+    model._cholesky = {}                       # factors of a covariance matrix depend on the parameters (ANALYTICAL scheme)
+    for m in _leaf_models(model):
+        m._cholesky = {}
     for m in _leaf_models(model):
         n = len(m.model_params)
         if j < n:
             m.model_params[j] = torch.tensor(float(value), dtype=m.model_params[j].dtype)
+            if hasattr(model, "models"):       # ModelConfig keeps the concatenated list
+                model.model_params = [p for sub in model.models for p in sub.get_model_params()]
             return
         j -= n
     raise IndexError("parameter index out of range")
