@@ -28,6 +28,9 @@ __global__ __launch_bounds__(MCX_BLOCK) void kt_bs(const KTArgs a)
     constexpr int P = 3;
     const K1Args& k = a.k1;
     const int64_t i = (int64_t)blockIdx.x * MCX_BLOCK + threadIdx.x;
+    __shared__ double bm_lds[INJECT ? 2 : MCX_BM_LDS_DOUBLES];        // table-driven Box-Muller (mcx_math.h)
+    const double* tab = nullptr;
+    if (!INJECT) { mcx_bm_load(bm_lds); tab = bm_lds; }
     if (i >= k.n) return;
     const double* p = k.slots[0].p;
     const Dual<P> sigma = dseed<P>(p[1], 1), rate = dseed<P>(p[2], 2);
@@ -56,7 +59,7 @@ __global__ __launch_bounds__(MCX_BLOCK) void kt_bs(const KTArgs a)
         const mcx_step sp = ldk_struct(&k.steps[step]);
         double z;
         if (INJECT) z = k.inject_z[(int64_t)step * k.ld + i];
-        else { double ua, z1; draw_pair(k.seed, path, (uint32_t)step, 0u, ua, z, z1); }
+        else { double ua, z1; draw_pair<true>(k.seed, path, (uint32_t)step, 0u, ua, z, z1, tab); }
         if (k.scheme == MCX_SCHEME_ANALYTICAL) {
             // w = chol(sigma^2 dt) z = sigma * (L / sigma) * z : the Cholesky factor carries the graph to sigma (model.py:56-64)
             const double sq_chol = ldk(k.chol + sp.chol_idx) / p[1];
@@ -80,6 +83,9 @@ __global__ __launch_bounds__(MCX_BLOCK) void kt_heston(const KTArgs a)
     constexpr int P = 7;
     const K1Args& k = a.k1;
     const int64_t i = (int64_t)blockIdx.x * MCX_BLOCK + threadIdx.x;
+    __shared__ double bm_lds[INJECT ? 2 : MCX_BM_LDS_DOUBLES];        // table-driven Box-Muller (mcx_math.h)
+    const double* tab = nullptr;
+    if (!INJECT) { mcx_bm_load(bm_lds); tab = bm_lds; }
     if (i >= k.n) return;
     const double* p = k.slots[0].p;
     const Dual<P> spot = dseed<P>(p[0], 0), sigma = dseed<P>(p[1], 1), rate = dseed<P>(p[2], 2), rho = dseed<P>(p[3], 3),
@@ -116,7 +122,7 @@ __global__ __launch_bounds__(MCX_BLOCK) void kt_heston(const KTArgs a)
             if (k.n_uniform) u = k.inject_u[(int64_t)step * k.ld + i];
         } else {
             double ua;
-            draw_pair(k.seed, path, (uint32_t)step, 0u, ua, z0, z1);
+            draw_pair<true>(k.seed, path, (uint32_t)step, 0u, ua, z0, z1, tab);
             if (k.n_uniform) { double t0, t1; draw_pair(k.seed, path, (uint32_t)step, 1u, u, t0, t1); }
         }
         if (k.scheme == MCX_SCHEME_EULER) {

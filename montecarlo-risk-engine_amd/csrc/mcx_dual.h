@@ -24,11 +24,11 @@ template <int P> __device__ __forceinline__ Dual<P> operator*(double c, const Du
 template <int P> __device__ __forceinline__ Dual<P> operator+(double c, const Dual<P>& a) { return a + c; }
 template <int P> __device__ __forceinline__ Dual<P> operator-(double c, const Dual<P>& a) { Dual<P> r; r.v = c - a.v; for (int j = 0; j < P; ++j) r.d[j] = -a.d[j]; return r; }
 template <int P> __device__ __forceinline__ Dual<P> operator/(double c, const Dual<P>& a) { return dconst<P>(c) / a; }
-template <int P> __device__ __forceinline__ Dual<P> dexp(const Dual<P>& a) { Dual<P> r; r.v = exp(a.v); for (int j = 0; j < P; ++j) r.d[j] = r.v * a.d[j]; return r; }
-template <int P> __device__ __forceinline__ Dual<P> dlog(const Dual<P>& a) { Dual<P> r; r.v = log(a.v); const double ia = 1.0 / a.v; for (int j = 0; j < P; ++j) r.d[j] = a.d[j] * ia; return r; }
+template <int P> __device__ __forceinline__ Dual<P> dexp(const Dual<P>& a) { Dual<P> r; r.v = mcx_exp(a.v); for (int j = 0; j < P; ++j) r.d[j] = r.v * a.d[j]; return r; }
+template <int P> __device__ __forceinline__ Dual<P> dlog(const Dual<P>& a) { Dual<P> r; r.v = mcx_log(a.v); const double ia = 1.0 / a.v; for (int j = 0; j < P; ++j) r.d[j] = a.d[j] * ia; return r; }
 // sqrt: a zero tangent stays zero even where 1/(2 sqrt(x)) is infinite (x clamped to 0).  Reverse mode gets the same result
 // because torch.clamp's backward is a `where(mask, grad, 0)` that discards the inf/NaN produced by sqrt's backward.
-template <int P> __device__ __forceinline__ Dual<P> dsqrt(const Dual<P>& a) { Dual<P> r; r.v = sqrt(a.v); const double h = 0.5 / r.v; for (int j = 0; j < P; ++j) r.d[j] = a.d[j] == 0.0 ? 0.0 : a.d[j] * h; return r; }
+template <int P> __device__ __forceinline__ Dual<P> dsqrt(const Dual<P>& a) { Dual<P> r; r.v = mcx_sqrt(a.v); const double h = 0.5 / r.v; for (int j = 0; j < P; ++j) r.d[j] = a.d[j] == 0.0 ? 0.0 : a.d[j] * h; return r; }
 // torch.clamp(x, min=lo): gradient mask x >= lo
 template <int P> __device__ __forceinline__ Dual<P> dclamp_min(const Dual<P>& a, double lo) { Dual<P> r; const bool pass = a.v >= lo; r.v = pass ? a.v : lo; for (int j = 0; j < P; ++j) r.d[j] = pass ? a.d[j] : 0.0; return r; }
 template <int P> __device__ __forceinline__ Dual<P> dclamp(const Dual<P>& a, double lo, double hi) { Dual<P> r; const bool pass = a.v >= lo && a.v <= hi; r.v = fmin(fmax(a.v, lo), hi); for (int j = 0; j < P; ++j) r.d[j] = pass ? a.d[j] : 0.0; return r; }
