@@ -283,3 +283,28 @@ def test_forward_mode_cva_against_reference_autograd_and_bumps(hip):
         scale = np.abs(out[False][k]).max()
         assert np.allclose(out[True][k], out[False][k], rtol=2e-5, atol=2e-6 * scale), (k, out[True][k], out[False][k])
     assert np.allclose(out[True][2], out[False][2], rtol=1e-12)
+
+
+def test_table_box_muller_normals_moments_and_tails(hip):
+    """the table-driven Box-Muller of the path kernels (mcx_math.h): both outputs of a draw (cos and sin branch) over 2 x 2^24
+    samples — mean, variance, skewness, kurtosis, cross-correlation and the 4-sigma / 5-sigma tail masses of N(0,1)"""
+    n = 1 << 24
+    models = [cases.BlackScholesModel(0.0, 1.0, 0.0, 1.0, asset_id=a) for a in ("a", "b")]
+    model = cases.ModelConfig(models=models, inter_asset_correlation_matrix=np.array([[0.0]]))
+    eng = cases.MonteCarloEngine(np.array([1.0]), cases.A, model, n, 1, backend=hip) if hasattr(cases, "MonteCarloEngine") else None
+    if eng is None:
+        from mcx.engine.engine import MonteCarloEngine
+        eng = MonteCarloEngine(np.array([1.0]), cases.A, model, n, 1, backend=hip)
+    p = eng.generate_paths_native()                       # [1][2][n]: S_T = exp(-0.5 + z)
+    z = torch.log(p[0]) + 0.5
+    for k in range(2):
+        x = z[k]
+        m, v = float(x.mean()), float(x.var())
+        s = float(((x - m) ** 3).mean()) / v ** 1.5
+        kurt = float(((x - m) ** 4).mean()) / v ** 2
+        assert abs(m) < 5 / np.sqrt(n) and abs(v - 1) < 5 * np.sqrt(2 / n), (k, m, v)
+        assert abs(s) < 5 * np.sqrt(6 / n) and abs(kurt - 3) < 5 * np.sqrt(24 / n), (k, s, kurt)
+        for thr, prob in ((4.0, 6.334248366623973e-05), (5.0, 5.733031437583878e-07)):
+            cnt, exp = int((x.abs() > thr).sum()), prob * n
+            assert abs(cnt - exp) < 5 * np.sqrt(exp) + 3, (k, thr, cnt, exp)
+    assert abs(float((z[0] * z[1]).mean())) < 5 / np.sqrt(n)
