@@ -257,7 +257,8 @@ class SimulationController:
                             t_start += 1
                         num, x = expo_atoms(p.asset_ids[0])[i]
                         if analytic:
-                            aux = (self.model._pf(1), self.model._pf(2), float(p.exercise_date[0]) - t, 0.0)
+                            _s, sig_p, rate_p = p._bs_inputs(self.model)
+                            aux = (sig_p, rate_p, float(p.exercise_date[0]) - t, 0.0)
                             comp.add_event(_abi.EV_EXPO_BS, comp.tidx(t), num, x, (0, 0), -1, i, p._K, p._sign(), aux)
                         else:
                             comp.add_event(_abi.EV_EXPO_POLY, comp.tidx(t), num, x, (0, 0),
