@@ -45,7 +45,7 @@ extern "C" {
 #define MCX_SLOT_NPARAM 8
 #define MCX_AUX         8    /* host-precomputed per-(sub-step, slot) constants                 */
 #define MCX_MAX_BASIS   6    /* regression basis functions (polynomial degree + 1)              */
-#define MCX_MAX_STATES  4    /* product exercise states (Bermudan: 2)                           */
+#define MCX_MAX_STATES  8    /* product exercise states (Bermudan: 2, FlexiCall: rights + 1)    */
 
 /* SimulationScheme values mirror common/enums.py:4-9 */
 enum { MCX_SCHEME_EULER = 0, MCX_SCHEME_MILSTEIN = 1, MCX_SCHEME_ANALYTICAL = 2, MCX_SCHEME_QE = 3 };

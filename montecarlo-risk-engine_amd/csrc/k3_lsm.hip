@@ -411,6 +411,10 @@ extern "C" int mcx_lsm_step(mcx_handle* h, const mcx_book* b, int32_t product, i
     case 2: rc = dispatch_k3<2>(K, a, grid, mfma, s); break;
     case 3: rc = dispatch_k3<3>(K, a, grid, mfma, s); break;
     case 4: rc = dispatch_k3<4>(K, a, grid, mfma, s); break;
+    case 5: rc = dispatch_k3<5>(K, a, grid, mfma, s); break;
+    case 6: rc = dispatch_k3<6>(K, a, grid, mfma, s); break;
+    case 7: rc = dispatch_k3<7>(K, a, grid, mfma, s); break;
+    case 8: rc = dispatch_k3<8>(K, a, grid, mfma, s); break;
     default: break;
     }
     if (rc != 0) MCX_FAIL(h, -3, "mcx_lsm_step: unsupported (basis=%d, states=%d)", K, S);
@@ -470,6 +474,10 @@ extern "C" int mcx_lsm_step_batch(mcx_handle* h, const mcx_book* b, const mcx_ls
         case 2: rc = dispatch_k3_batch<2>(K, a, d_jobs, grid, s); break;
         case 3: rc = dispatch_k3_batch<3>(K, a, d_jobs, grid, s); break;
         case 4: rc = dispatch_k3_batch<4>(K, a, d_jobs, grid, s); break;
+        case 5: rc = dispatch_k3_batch<5>(K, a, d_jobs, grid, s); break;
+        case 6: rc = dispatch_k3_batch<6>(K, a, d_jobs, grid, s); break;
+        case 7: rc = dispatch_k3_batch<7>(K, a, d_jobs, grid, s); break;
+        case 8: rc = dispatch_k3_batch<8>(K, a, d_jobs, grid, s); break;
         default: rc = -1; break;
         }
         if (rc != 0) break;

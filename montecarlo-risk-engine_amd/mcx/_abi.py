@@ -12,7 +12,7 @@ MAX_STATE = 16
 SLOT_NPARAM = 8
 AUX = 8
 MAX_BASIS = 6
-MAX_STATES = 4
+MAX_STATES = 8
 
 SCHEME_EULER, SCHEME_MILSTEIN, SCHEME_ANALYTICAL, SCHEME_QE = 0, 1, 2, 3
 MODEL_BS, MODEL_HESTON, MODEL_VASICEK, MODEL_CIRPP, MODEL_CIRPP_DET, MODEL_HW = 1, 2, 3, 4, 5, 6

@@ -86,6 +86,10 @@ class CIRPPModel(Model):
         """deterministic shift fitting the market curve: psi(t) = lambda_mkt(t) + D(t) - y0 E(t)  (cirpp.py:137-142)"""
         return self._lambda_market(t) + self._D(t) - self._pf(3) * self._E(t)
 
+    def lambda_t(self, t, y_t):
+        """default intensity lambda(t) = y_t + psi(t)  (cirpp.py:144-147)"""
+        return y_t + self.psi(float(t))
+
     def _cond_survival_coeffs(self, t, T) -> tuple[float, float]:
         """S(t,T | y) = c * exp(-B(t,T) y)  (cirpp.py:246-285); returns (c, B)"""
         t, T = float(t), float(T)

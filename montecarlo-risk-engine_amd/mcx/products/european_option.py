@@ -138,6 +138,26 @@ class EuropeanOption(Product):
         params = (kappa, theta, sigma, rho, v0)
         return spot * self._Qj(1, spot, K, T, rate, params) - K * math.exp(-rate * T) * self._Qj(2, spot, K, T, rate, params)
 
+    def compute_pv_bond_option_analytically(self, model):
+        """European option on a zero-coupon bond under Vasicek (Jamshidian closed form, european_option.py:264-288)"""
+        from .bond import Bond
+        if not isinstance(self.underlying, Bond):
+            raise TypeError("Expected self.underlying to be of type Bond")
+        a, rate, sigma, t0 = model._pf(3), model._pf(0), model._pf(1), model.t0()
+        T, S = self._T, float(self.underlying.maturity[0]) if hasattr(self.underlying.maturity, "__len__") else float(self.underlying.maturity)
+        p_T = float(model.compute_bond_price(t0, T, torch.tensor([rate], dtype=FLOAT))[0])
+        p_S = float(model.compute_bond_price(t0, S, torch.tensor([rate], dtype=FLOAT))[0])
+        b_ts = (1.0 - math.exp(-a * (S - T))) / a
+        sig = sigma * math.sqrt((1.0 - math.exp(-2.0 * a * (T - t0))) / (2.0 * a)) * b_ts
+        if sig == 0.0:              # exercise at the bond's maturity: the closed form degenerates to the discounted intrinsic value
+            call = max(p_S - self._K * p_T, 0.0)
+            return torch.tensor([call if self.option_type == OptionType.CALL else call - (p_S - self._K * p_T)], dtype=FLOAT)
+        d1 = (math.log(p_S / (p_T * self._K)) + 0.5 * sig * sig) / sig
+        d2 = d1 - sig
+        if self.option_type == OptionType.CALL:
+            return torch.tensor([p_S * _norm_cdf(d1) - self._K * p_T * _norm_cdf(d2)], dtype=FLOAT)
+        return torch.tensor([self._K * p_T * _norm_cdf(-d2) - p_S * _norm_cdf(-d1)], dtype=FLOAT)
+
     def compute_pv_analytically_heston(self, model):
         from ..models.heston import HestonModel
         if not isinstance(model, HestonModel):
