@@ -56,6 +56,13 @@ class Shard:
         if not self.active or self.world == 1:
             return a[None]
         t = torch.from_numpy(a).to(self._comm_device())
+        if self.backend == "nccl" and not getattr(self, "_no_tensor_gather", False):
+            try:                                                        # one collective, one device-to-host copy
+                out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+                dist.all_gather_into_tensor(out, t, group=self.group)
+                return out.cpu().numpy()
+            except (RuntimeError, NotImplementedError):                 # deterministic on every rank: all fall back together
+                self._no_tensor_gather = True
         out = [torch.empty_like(t) for _ in range(self.world)]
         dist.all_gather(out, t, group=self.group)
         return np.stack([o.cpu().numpy() for o in out], axis=0)

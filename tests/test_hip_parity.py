@@ -308,3 +308,34 @@ def test_table_box_muller_normals_moments_and_tails(hip):
             cnt, exp = int((x.abs() > thr).sum()), prob * n
             assert abs(cnt - exp) < 5 * np.sqrt(exp) + 3, (k, thr, cnt, exp)
     assert abs(float((z[0] * z[1]).mean())) < 5 / np.sqrt(n)
+
+
+def test_rccl_collectives_single_rank_group(hip):
+    """the collectives the N > 1 path uses (mcx/parallel.py: all_gather_into_tensor of accumulator records, all_reduce of LSM
+    moments / select histograms, broadcast) on a one-rank RCCL group: proves the backend initialises on this stack; the
+    multi-rank logic itself is covered by the 2-rank gloo tests"""
+    import os
+    import torch.distributed as dist
+    if dist.is_initialized():
+        pytest.skip("a process group already exists")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        from mcx.parallel import Shard
+        sh = Shard()
+        assert sh.active and sh.backend == "nccl" and sh.split(10) == (0, 10)
+        rec = torch.arange(8, dtype=torch.float64, device="cuda").reshape(2, 4)
+        out = torch.empty((1, 2, 4), dtype=torch.float64, device="cuda")
+        dist.all_gather_into_tensor(out, rec)
+        assert torch.equal(out[0], rec)
+        t = torch.ones(5, dtype=torch.float64, device="cuda")
+        dist.all_reduce(t)
+        dist.broadcast(t, 0)
+        assert float(t.sum()) == 5.0
+        sc, _ = cases.make_controller("irs_cva", hip, inject=False)       # a whole run with an active (one-rank) process group
+        a = sc.run_simulation().results[0][0][0]
+    finally:
+        dist.destroy_process_group()
+    sc2, _ = cases.make_controller("irs_cva", hip, inject=False)
+    b = sc2.run_simulation().results[0][0][0]
+    assert a[0] == b[0]
