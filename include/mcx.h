@@ -163,7 +163,10 @@ typedef struct {
                               clamp((x + aux[2]) / (2 aux[2]), 0, 1) of maths.py:3-9, binary_option.py:38-43;
                               4: discretely monitored barrier option (barrier_option.py:60-125): the terms are the
                               monitored spots, x_atom the spot at maturity, aux[1] / aux[2] the barrier levels,
-                              aux[3] = type1 + 8 * type2 (1 up-out, 2 down-out, 3 up-in, 4 down-in; type2 0 = none))   */
+                              aux[3] = type1 + 8 * type2 (1 up-out, 2 down-out, 3 up-in, 4 down-in; type2 0 = none);
+                              5: mode 4 with the Brownian-bridge crossing correction (barrier_option.py:126-223):
+                              coeffs[coeff_off] = -2 / (sigma^2 maturity / n_obs), coeffs[coeff_off + 1] = draw id;
+                              uniforms per mcx_book_set_bridge_rng)                                              */
 } mcx_event;
 
 typedef struct {
@@ -368,6 +371,14 @@ int  mcx_lsm_step_batch(mcx_handle* h, const mcx_book* book, const mcx_lsm_job* 
 /* coeffs[h_offsets[j] + q] = h_values[j * len + q], q < len, for n blocks in one call (the batched form of mcx_book_set_coeffs) */
 int  mcx_book_set_coeffs_batch(mcx_handle* h, mcx_book* book, const int64_t* h_offsets, int32_t n, int32_t len,
                                const double* h_values, void* stream);
+
+/* RNG of the Brownian-bridge barrier events (OPTION mode 5), set before mcx_eval_book / mcx_lsm_step*: one uniform per monitored
+ * interval k and barrier b from Philox4x32-10 with key = seed and counter = (global path id = path_offset + i, k,
+ * 0x80000000 | (2 * draw_id + b)).  The reference draws them from a numpy Generator on the host (barrier_option.py:52-53, 163,
+ * 187); a parity run injects those numbers: h_inject[product] = device pointer to [2 * n_intervals][ld] uniforms (row 2k + b),
+ * NULL entries / NULL table = Philox. */
+int  mcx_book_set_bridge_rng(mcx_handle* h, mcx_book* book, uint64_t seed, uint64_t path_offset, const double* const* h_inject,
+                             int64_t ld, void* stream);
 
 /* K4 — reductions. Every output record is an mcx_acc (host memory, valid on return).
  * mcx_reduce_vector  : PVMetric on cfs (pv_metric.py:17-18)                                   h_out[1]

@@ -10,7 +10,7 @@
 // loads and scalar branches; all HBM accesses are 512-byte coalesced rows of the [date][state][path] layout.
 #include <algorithm>
 
-#include "mcx_internal.h"
+#include "mcx_device.h"
 
 namespace {
 
@@ -28,6 +28,7 @@ struct K2Args {
     // product-chunked mode (big books on few paths): blockIdx.y = chunk of `chunk_products` consecutive products, each chunk
     // ACCUMULATES into its own zero-initialised [n_ns][*][ld_out] image (cfs / expo then point at the chunk images)
     int32_t chunk_products, n_netting_sets;
+    const DevBridge* __restrict__ bridge;       // RNG state of Brownian-bridge barrier events (device struct of the book)
 };
 
 __device__ __forceinline__ double dev_poly(const double* __restrict__ c, int K, double x)
@@ -42,22 +43,12 @@ __device__ __forceinline__ double dev_norm_cdf(double x) { return 0.5 * (1.0 + e
 // normalised cashflow of one product-date event for a path in exercise state s (s may be decremented)
 __device__ __forceinline__ double dev_cash_event(const DevEvent& e, const DevTerm* __restrict__ terms, const DevAtom* __restrict__ atoms,
                                                  const double* __restrict__ coeffs, int K, const double* __restrict__ paths,
-                                                 int64_t D, int64_t ld, int64_t i, int& s)
+                                                 int64_t D, int64_t ld, int64_t i, int& s, const DevBridge* __restrict__ bridge)
 {
     const double num = dev_atom(e.num, paths, D, ld, i);
     double common = 0.0, own = 0.0, glog = 0.0;
-    if (e.kind == MCX_EV_OPTION && e.aux[0] == 4.0) {                     // barrier option, discrete monitoring (barrier_option.py:60-125)
-        double mx = -1.0e300, mn = 1.0e300;
-        AtomCache bc = {-1, -1, 0.0};
-        for (int j = e.term_begin; j < e.term_end; ++j) {
-            const double s = dev_atom_cached(ldk_struct(&terms[j]).atom, paths, D, ld, i, bc);
-            mx = fmax(mx, s); mn = fmin(mn, s);
-        }
-        const int types = (int)e.aux[3];
-        double pay = fmax(e.sign * (dev_atom(e.x, paths, D, ld, i) - e.strike), 0.0) * dev_barrier_ind(types & 7, e.aux[1], mx, mn);
-        if (types >> 3) pay *= dev_barrier_ind(types >> 3, e.aux[2], mx, mn);
-        return pay / num;
-    }
+    if (e.kind == MCX_EV_OPTION && (e.aux[0] == 4.0 || e.aux[0] == 5.0))      // barrier options (barrier_option.py:60-223)
+        return dev_barrier_event(e, terms, coeffs, bridge, paths, D, ld, i, num);
     if (e.kind == MCX_EV_OPTION && e.aux[0] == 3.0) {                     // binary payoff (binary_option.py:38-43): fuzzy indicator
         double val = 0.0;
         AtomCache bc = {-1, -1, 0.0};
@@ -127,7 +118,7 @@ __global__ __launch_bounds__(MCX_BLOCK) void k2_eval_book(const K2Args a)
         for (int q = pr.ev_begin; q < pr.ev_end; ++q) {
             const DevEvent e = ldk_struct(&a.events[q]);
             if (e.kind <= MCX_EV_EXERCISE) {
-                acc += dev_cash_event(e, a.terms, a.atoms, a.coeffs, K, a.paths, D, ld, i, s);
+                acc += dev_cash_event(e, a.terms, a.atoms, a.coeffs, K, a.paths, D, ld, i, s, a.bridge);
             } else {
                 double v = 0.0;
                 if (e.kind == MCX_EV_EXPO_POLY) {
@@ -197,7 +188,7 @@ extern "C" int mcx_eval_book(mcx_handle* h, const mcx_book* b, const double* d_p
     a.paths = d_paths; a.cfs = d_cfs; a.expo = d_expo; a.n = n_paths; a.ld = ld; a.ld_out = ld_out;
     a.n_products = b->n_products; a.n_basis = b->n_basis; a.n_state = b->n_state; a.n_expo_rows = b->n_expo_rows;
     a.want_cfs = b->want_cfs; a.want_expo = b->want_expo;
-    a.chunk_products = 0; a.n_netting_sets = b->n_netting_sets;
+    a.chunk_products = 0; a.n_netting_sets = b->n_netting_sets; a.bridge = b->d_bridge;
     const int grid = (int)((n_paths + MCX_BLOCK - 1) / MCX_BLOCK);
     // Few paths x many products (the reference's 5,000-product books run on ~1,000 paths): the path grid alone leaves the
     // chip empty (4 workgroups) while every lane walks ~10^6 events.  Split the PRODUCT list over blockIdx.y instead; each

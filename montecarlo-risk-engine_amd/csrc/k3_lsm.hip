@@ -11,7 +11,7 @@
 //     v_mfma_f64_16x16x4_f64 — A = F^T (16 features x 4 paths), B = F (4 paths x 16 features) per instruction; the
 //     features of 64 paths are staged through LDS in a bank-conflict-free [feature][path] image (row stride 66 doubles).
 // Both read each path's state once (HBM-bound: 8*(1+S+atoms) B/path).
-#include "mcx_internal.h"
+#include "mcx_device.h"
 
 namespace {
 
@@ -27,6 +27,7 @@ struct K3Args {
     double shift, scale;
     int64_t n, ld, ld_w;
     int32_t roll_begin, roll_end, n_basis, n_state, f32_cache;
+    const DevBridge* __restrict__ bridge;
 };
 
 __device__ __forceinline__ double k3_poly(const double* __restrict__ c, int K, double x)
@@ -40,18 +41,8 @@ __device__ __forceinline__ double k3_cash_event(const DevEvent& e, const K3Args&
 {
     const double num = dev_atom(e.num, a.paths, D, a.ld, i);
     double common = 0.0, own = 0.0, glog = 0.0;
-    if (e.kind == MCX_EV_OPTION && e.aux[0] == 4.0) {                     // barrier option, discrete monitoring (barrier_option.py:60-125)
-        double mx = -1.0e300, mn = 1.0e300;
-        AtomCache bc = {-1, -1, 0.0};
-        for (int j = e.term_begin; j < e.term_end; ++j) {
-            const double s = dev_atom_cached(ldk_struct(&a.terms[j]).atom, a.paths, D, a.ld, i, bc);
-            mx = fmax(mx, s); mn = fmin(mn, s);
-        }
-        const int types = (int)e.aux[3];
-        double pay = fmax(e.sign * (dev_atom(e.x, a.paths, D, a.ld, i) - e.strike), 0.0) * dev_barrier_ind(types & 7, e.aux[1], mx, mn);
-        if (types >> 3) pay *= dev_barrier_ind(types >> 3, e.aux[2], mx, mn);
-        return pay / num;
-    }
+    if (e.kind == MCX_EV_OPTION && (e.aux[0] == 4.0 || e.aux[0] == 5.0))      // barrier options (barrier_option.py:60-223)
+        return dev_barrier_event(e, a.terms, a.coeffs, a.bridge, a.paths, D, a.ld, i, num);
     if (e.kind == MCX_EV_OPTION && e.aux[0] == 3.0) {                     // binary payoff (binary_option.py:38-43): fuzzy indicator
         double val = 0.0;
         AtomCache bc = {-1, -1, 0.0};
@@ -403,7 +394,7 @@ extern "C" int mcx_lsm_step(mcx_handle* h, const mcx_book* b, int32_t product, i
     a.terms = b->d_terms; a.events = b->d_events + pr.cf_begin; a.atoms = b->d_atoms; a.coeffs = b->d_coeffs; a.paths = d_paths;
     a.W = d_W; a.partials = h->d_ws; a.num = flat(num_atom); a.x = flat(x_atom); a.shift = shift; a.scale = scale;
     a.n = n_paths; a.ld = ld; a.ld_w = ld_w; a.roll_begin = roll_begin; a.roll_end = roll_end; a.n_basis = K; a.n_state = b->n_state;
-    a.f32_cache = (flags & MCX_LSM_F32_CACHE) ? 1 : 0;
+    a.f32_cache = (flags & MCX_LSM_F32_CACHE) ? 1 : 0; a.bridge = b->d_bridge;
     const bool mfma = (flags & MCX_LSM_MFMA) != 0;
     int rc = -1;
     switch (S) {
@@ -463,7 +454,7 @@ extern "C" int mcx_lsm_step_batch(mcx_handle* h, const mcx_book* b, const mcx_ls
     memset(&a, 0, sizeof(a));
     a.terms = b->d_terms; a.events = b->d_events; a.atoms = b->d_atoms; a.coeffs = b->d_coeffs; a.paths = d_paths;
     a.W = d_W; a.partials = d_part; a.n = n_paths; a.ld = ld; a.ld_w = ld_w; a.n_basis = K; a.n_state = b->n_state;
-    a.f32_cache = (flags & MCX_LSM_F32_CACHE) ? 1 : 0;
+    a.f32_cache = (flags & MCX_LSM_F32_CACHE) ? 1 : 0; a.bridge = b->d_bridge;
     int rc = 0;
     for (int j0 = 0; j0 < n_jobs && rc == 0; j0 += chunk) {
         const int nj = n_jobs - j0 < chunk ? n_jobs - j0 : chunk;

@@ -636,7 +636,7 @@ extern "C" int mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_boo
             fe.kind = e.kind; fe.flags = e.flags; fe.coeff_off = e.coeff_off; fe.row = e.row; fe.ns = pr.netting_set; fe.sidx = sidx;
             fe.init_state = pr.init_state; fe.strike = e.strike; fe.sign = e.sign;
             for (int w = 0; w < 4; ++w) fe.aux[w] = e.aux[w];
-            if (e.kind == MCX_EV_OPTION && e.aux[0] == 4.0) { ok = false; why = "barrier monitoring is evaluated by the book kernel (K2)"; }
+            if (e.kind == MCX_EV_OPTION && (e.aux[0] == 4.0 || e.aux[0] == 5.0)) { ok = false; why = "barrier monitoring is evaluated by the book kernel (K2)"; }
             fe.num = fatom(devatom_to_mcx(e.num), t);
             fe.x = fatom(devatom_to_mcx(e.x), t);
             std::vector<FTerm>& terms = terms_by_date[t];

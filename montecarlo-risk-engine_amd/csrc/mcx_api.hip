@@ -1,5 +1,5 @@
 // mcx_api.hip — handle, book (descriptor flattening + upload) and small shared host helpers of libmcx_hip.so.
-#include "mcx_internal.h"
+#include "mcx_device.h"
 
 extern "C" int mcx_abi_version(void) { return MCX_ABI_VERSION; }
 
@@ -70,7 +70,9 @@ extern "C" int mcx_book_create(mcx_handle* h, const mcx_book_desc* d, mcx_book**
             MCX_FAIL(h, -3, "mcx_book_create: event %d coefficient offset", i);
         if ((e.kind == MCX_EV_EXERCISE && e.coeff_off >= 0 && e.x_atom < 0) || (e.kind >= MCX_EV_EXPO_POLY && e.x_atom < 0))
             MCX_FAIL(h, -3, "mcx_book_create: event %d needs an explanatory atom", i);
-        if (e.kind == MCX_EV_OPTION && e.aux[0] == 4.0 && (e.x_atom < 0 || ((int)e.aux[3] & 7) < 1 || ((int)e.aux[3] & 7) > 4 || ((int)e.aux[3] >> 3) > 4))
+        if (e.kind == MCX_EV_OPTION && e.aux[0] == 5.0 && (e.coeff_off < 0 || e.coeff_off + 2 > d->n_coeffs))
+            MCX_FAIL(h, -3, "mcx_book_create: bridge barrier event %d needs two parameters at coeff_off", i);
+        if (e.kind == MCX_EV_OPTION && (e.aux[0] == 4.0 || e.aux[0] == 5.0) && (e.x_atom < 0 || ((int)e.aux[3] & 7) < 1 || ((int)e.aux[3] & 7) > 4 || ((int)e.aux[3] >> 3) > 4))
             MCX_FAIL(h, -3, "mcx_book_create: barrier event %d needs the maturity spot in x_atom and barrier types in 1..4", i);
         if (e.kind == MCX_EV_OPTION && e.aux[0] == 3.0 && !(e.aux[2] > 0.0)) MCX_FAIL(h, -3, "mcx_book_create: binary event %d needs eps > 0", i);
         if (e.kind >= MCX_EV_EXPO_POLY && (e.expo_row < 0 || e.expo_row >= d->n_expo_rows)) MCX_FAIL(h, -3, "mcx_book_create: event %d row", i);
@@ -83,13 +85,15 @@ extern "C" int mcx_book_create(mcx_handle* h, const mcx_book_desc* d, mcx_book**
             MCX_FAIL(h, -3, "mcx_book_create: product %d out of range", p);
         for (int q = pr.ev_begin; q < pr.ev_end; ++q) {
             const mcx_event& e = d->events[q];
-            if (e.coeff_off >= 0 && e.coeff_off + pr.n_states * d->n_basis > d->n_coeffs)
+            const bool bridge = e.kind == MCX_EV_OPTION && e.aux[0] == 5.0;      // coeff_off = two parked parameters, checked above
+            if (!bridge && e.coeff_off >= 0 && e.coeff_off + pr.n_states * d->n_basis > d->n_coeffs)
                 MCX_FAIL(h, -3, "mcx_book_create: product %d event %d coefficients out of range", p, q);
         }
         for (int q = pr.cf_begin; q < pr.cf_end; ++q) {
             const mcx_event& e = d->events[q];
             if (e.kind > MCX_EV_EXERCISE) MCX_FAIL(h, -3, "mcx_book_create: product %d cf event %d is not a cash event", p, q);
-            if (e.coeff_off >= 0 && e.coeff_off + pr.n_states * d->n_basis > d->n_coeffs)
+            const bool bridge = e.kind == MCX_EV_OPTION && e.aux[0] == 5.0;
+            if (!bridge && e.coeff_off >= 0 && e.coeff_off + pr.n_states * d->n_basis > d->n_coeffs)
                 MCX_FAIL(h, -3, "mcx_book_create: product %d cf event %d coefficients out of range", p, q);
         }
     }
@@ -153,11 +157,15 @@ extern "C" int mcx_book_create(mcx_handle* h, const mcx_book_desc* d, mcx_book**
             if (!b->ns_has_writer[q]) b->expo_needs_memset = true;
 
     b->d_atoms = nullptr; b->d_terms = nullptr; b->d_events = nullptr; b->d_products = nullptr; b->d_coeffs = nullptr;
+    b->d_bridge = nullptr; b->d_bridge_inject = nullptr;
     MCX_HIP(h, hipMalloc(&b->d_atoms, sizeof(DevAtom) * atoms.size()));
     MCX_HIP(h, hipMalloc(&b->d_terms, sizeof(DevTerm) * terms.size()));
     MCX_HIP(h, hipMalloc(&b->d_events, sizeof(DevEvent) * events.size()));
     MCX_HIP(h, hipMalloc(&b->d_products, sizeof(DevProduct) * (b->h_products.size() ? b->h_products.size() : 1)));
     MCX_HIP(h, hipMalloc(&b->d_coeffs, sizeof(double) * (size_t)(d->n_coeffs > 0 ? d->n_coeffs : 1)));
+    MCX_HIP(h, hipMalloc(&b->d_bridge, sizeof(DevBridge)));
+    MCX_HIP(h, hipMemset(b->d_bridge, 0, sizeof(DevBridge)));
+    MCX_HIP(h, hipMalloc(&b->d_bridge_inject, sizeof(double*) * (size_t)(d->n_products > 0 ? d->n_products : 1)));
     MCX_HIP(h, hipMemcpy(b->d_atoms, atoms.data(), sizeof(DevAtom) * atoms.size(), hipMemcpyHostToDevice));
     MCX_HIP(h, hipMemcpy(b->d_terms, terms.data(), sizeof(DevTerm) * terms.size(), hipMemcpyHostToDevice));
     MCX_HIP(h, hipMemcpy(b->d_events, events.data(), sizeof(DevEvent) * events.size(), hipMemcpyHostToDevice));
@@ -173,6 +181,7 @@ extern "C" void mcx_book_destroy(mcx_book* b)
 {
     if (!b) return;
     hipFree(b->d_atoms); hipFree(b->d_terms); hipFree(b->d_events); hipFree(b->d_products); hipFree(b->d_coeffs);
+    hipFree(b->d_bridge); hipFree(b->d_bridge_inject);
     delete b;
 }
 
@@ -192,6 +201,22 @@ extern "C" int mcx_book_set_coeffs(mcx_handle* h, mcx_book* b, int64_t offset, i
         MCX_HIP(h, hipStreamSynchronize(s));
         MCX_HIP(h, hipMemcpy(b->d_coeffs + offset, h_coeffs, (size_t)count * sizeof(double), hipMemcpyHostToDevice));
     }
+    return 0;
+}
+
+extern "C" int mcx_book_set_bridge_rng(mcx_handle* h, mcx_book* b, uint64_t seed, uint64_t path_offset, const double* const* h_inject,
+                                       int64_t ld, void* stream)
+{
+    if (!h || !b) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    MCX_HIP(h, hipStreamSynchronize(s));
+    DevBridge br;
+    br.seed = seed; br.path_offset = path_offset; br.inject = nullptr; br.ld = ld;
+    if (h_inject) {
+        MCX_HIP(h, hipMemcpy(b->d_bridge_inject, h_inject, sizeof(double*) * (size_t)b->n_products, hipMemcpyHostToDevice));
+        br.inject = b->d_bridge_inject;
+    }
+    MCX_HIP(h, hipMemcpy(b->d_bridge, &br, sizeof(br), hipMemcpyHostToDevice));
     return 0;
 }
 

@@ -58,6 +58,69 @@ __device__ __forceinline__ double u53(uint32_t lo, uint32_t hi)
     return fma((double)hi, 0x1.0p-32, fma((double)(lo >> 11), 0x1.0p-53, 0x1.0p-54));
 }
 
+
+// ---- barrier options (barrier_option.py:60-223): MCX_EV_OPTION modes 4 (discrete monitoring) and 5 (+ Brownian bridge) ------
+// RNG state of the bridge draws, one per book (mcx_book_set_bridge_rng): production draws are Philox4x32-10 with key = seed and
+// counter = (global path id, interval, 0x80000000 | (2 * draw_id + barrier)); a parity run injects the reference's uniforms.
+struct DevBridge {
+    uint64_t seed, path_offset;
+    const double* const* inject;     // [n_products] device pointers to [2 * n_intervals][ld] uniforms, or nullptr
+    int64_t ld;
+};
+
+__device__ __forceinline__ double dev_barrier_event(const DevEvent& e, const DevTerm* __restrict__ terms, const double* __restrict__ coeffs,
+                                                    const DevBridge* __restrict__ bridge, const double* __restrict__ paths, int64_t D,
+                                                    int64_t ld, int64_t i, double num)
+{
+    const int types = (int)e.aux[3];
+    const int t1 = types & 7, t2 = types >> 3;
+    const bool with_bridge = e.aux[0] == 5.0;
+    double mx = -1.0e300, mn = 1.0e300, keep1 = 1.0, keep2 = 1.0, prev1 = 0.0, prev2 = 0.0;
+    double c = 0.0;
+    int draw_id = 0;
+    DevBridge br = {0, 0, nullptr, 0};
+    const double* __restrict__ inj = nullptr;
+    if (with_bridge) {
+        c = ldk(coeffs + e.coeff_off);                       // -2 / (sigma^2 * maturity / n_observations)   (:146)
+        draw_id = (int)ldk(coeffs + e.coeff_off + 1);
+        br = ldk_struct(bridge);
+        if (br.inject) inj = br.inject[draw_id];
+    }
+    AtomCache bc = {-1, -1, 0.0};
+    for (int j = e.term_begin; j < e.term_end; ++j) {
+        const double s = dev_atom_cached(ldk_struct(&terms[j]).atom, paths, D, ld, i, bc);
+        mx = fmax(mx, s); mn = fmin(mn, s);
+        if (with_bridge) {
+            const double cur1 = mcx_log(s / e.aux[1]), cur2 = t2 ? mcx_log(s / e.aux[2]) : 0.0;
+            if (j > e.term_begin) {
+                const int k = j - e.term_begin - 1;          // interval index
+                for (int bi = 0; bi < (t2 ? 2 : 1); ++bi) {
+                    const double p = mcx_exp(c * (bi ? prev2 * cur2 : prev1 * cur1));      // crossing probability of the bridge
+                    double u;
+                    if (inj) u = inj[(int64_t)(2 * k + bi) * br.ld + i];
+                    else {
+                        uint32_t w0, w1, w2, w3;
+                        const uint64_t path = br.path_offset + (uint64_t)i;
+                        philox4x32_10((uint32_t)path, (uint32_t)(path >> 32), (uint32_t)k, 0x80000000u | (uint32_t)(2 * draw_id + bi),
+                                      (uint32_t)br.seed, (uint32_t)(br.seed >> 32), w0, w1, w2, w3);
+                        u = u53(w0, w1);
+                    }
+                    const double hit = fmin(fmax((p - u + 0.05) / 0.1, 0.0), 1.0);         // compute_degree_of_truth(p - u, True)
+                    if (bi) keep2 *= 1.0 - hit; else keep1 *= 1.0 - hit;
+                }
+            }
+            prev1 = cur1; prev2 = cur2;
+        }
+    }
+    double pay = fmax(e.sign * (dev_atom(e.x, paths, D, ld, i) - e.strike), 0.0) * dev_barrier_ind(t1, e.aux[1], mx, mn);
+    if (with_bridge) pay *= (t1 <= 2) ? keep1 : 1.0 - keep1;          // out: never hit; in: hit at least once
+    if (t2) {
+        pay *= dev_barrier_ind(t2, e.aux[2], mx, mn);
+        if (with_bridge) pay *= (t2 <= 2) ? keep2 : 1.0 - keep2;
+    }
+    return pay / num;
+}
+
 // one draw = two uniforms in (0,1) and their Box-Muller pair (include/mcx.h "RNG contract")
 // TAB: `tab` is the block's LDS copy of the Box-Muller tables (mcx_bm_load); otherwise polynomial log / sincos
 template <bool TAB = false>

@@ -78,6 +78,8 @@ struct mcx_book {
     DevEvent* d_events;
     DevProduct* d_products;
     double* d_coeffs;
+    struct DevBridge* d_bridge;      // RNG state of Brownian-bridge barrier events (mcx_device.h), one device struct per book
+    const double** d_bridge_inject;  // [n_products] device table of injected-uniform pointers (nullptr entries allowed)
     std::vector<mcx_atom> h_atoms;
     std::vector<DevEvent> h_events;
     std::vector<DevTerm> h_terms;

@@ -21,7 +21,7 @@ _EXPORTS = [
     "mcx_abi_version", "mcx_create", "mcx_destroy", "mcx_last_error", "mcx_device_info",
     "mcx_sim_create", "mcx_sim_destroy", "mcx_generate_paths",
     "mcx_book_create", "mcx_book_destroy", "mcx_book_set_coeffs", "mcx_eval_book", "mcx_resolve_atoms",
-    "mcx_lsm_stats", "mcx_lsm_step", "mcx_lsm_step_batch", "mcx_book_set_coeffs_batch",
+    "mcx_lsm_stats", "mcx_lsm_step", "mcx_lsm_step_batch", "mcx_book_set_coeffs_batch", "mcx_book_set_bridge_rng",
     "mcx_tangent_paths", "mcx_tangent_lsm", "mcx_tangent_eval", "mcx_tangent_cva", "mcx_tangent_profiles",
     "mcx_tangent_european", "mcx_fused_create", "mcx_fused_destroy", "mcx_fused_num_records", "mcx_fused_run", "mcx_fused_eval_paths",
     "mcx_reduce_vector", "mcx_reduce_profiles", "mcx_reduce_cva", "mcx_unsecured", "mcx_select_hist",
@@ -140,6 +140,19 @@ class HipBackend:
         book.plan.coeffs[offset:offset + v.size] = v
         self._check(self.lib.mcx_book_set_coeffs(self.h, book.ptr, C.c_int64(offset), C.c_int64(v.size), _abi.ptr(v),
                                                  self._stream()), "mcx_book_set_coeffs")
+
+    def book_set_bridge_rng(self, book, seed: int, path_offset: int, inject: dict | None = None):
+        """inject: {product index: tensor [2 * n_intervals][n_paths]} of recorded uniforms (parity runs) or None (Philox)"""
+        table, ld = None, 0
+        if inject:
+            arr = (C.c_void_p * book.plan.desc.n_products)()
+            for p_i, t in inject.items():
+                assert t.is_contiguous() and t.dtype == torch.float64
+                arr[p_i] = t.data_ptr()
+                ld = t.shape[1]
+            table = arr
+        self._check(self.lib.mcx_book_set_bridge_rng(self.h, book.ptr, C.c_uint64(seed), C.c_uint64(path_offset), table,
+                                                     C.c_int64(ld), self._stream()), "mcx_book_set_bridge_rng")
 
     def eval_book(self, book, paths: torch.Tensor):
         plan = book.plan

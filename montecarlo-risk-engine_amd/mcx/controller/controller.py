@@ -209,6 +209,7 @@ class SimulationController:
         want_cfs = rm.requires_discounted_cashflows()
         prods = np.zeros(len(self.products), dtype=_abi.PRODUCT_DTYPE)
         self._expo_coeff_base, self._reg_coeff_base, self._cash_meta = [], [], []
+        self._extra_coeff_base = []
         self._mc_products = []
         off = 0
         for p_i, p in enumerate(self.products):
@@ -217,6 +218,8 @@ class SimulationController:
             off += E * S * K
             self._reg_coeff_base.append(off)
             off += len(p.regression_timeline) * S * K
+            self._extra_coeff_base.append(off)
+            off += p._n_extra_coeffs()
         expo_atom_cache: dict = {}
 
         def expo_atoms(asset):       # (numeraire, SPOT) atoms of every exposure date, once per asset
@@ -230,6 +233,7 @@ class SimulationController:
         for p_i, p in enumerate(self.products):
             S = p.get_num_states()
             skip = self._can_skip_monte_carlo_for_product(p)
+            comp.current_product = p_i
             cash = [] if skip else p._cash_events(comp)
             pdates = [float(t) for t in p.product_timeline]
             assert skip or len(cash) == len(pdates)
@@ -240,6 +244,10 @@ class SimulationController:
                 has_x = ce.kind == _abi.EV_EXERCISE or ce.x_time is not None or ce.x_asset is not None       # (an asset id may be None)
                 x = comp.atom(AtomicRequest(AtomicRequestType.SPOT), ce.x_asset, ce.time if ce.x_time is None else ce.x_time) if has_x else -1
                 co = -1 if ce.reg_idx is None else self._reg_coeff_base[p_i] + ce.reg_idx * S * K
+                if ce.coeff_params:
+                    co = self._extra_coeff_base[p_i]
+                    for k_, v_ in enumerate(ce.coeff_params):
+                        comp.coeff_init[co + k_] = float(v_)
                 return comp.add_event(ce.kind, comp.tidx(ce.time), num, x, comp.add_terms(ce.terms), co, -1, ce.strike, ce.sign, ce.aux)
 
             cf_begin = len(comp.events)
@@ -336,6 +344,7 @@ class SimulationController:
             eng.inject_z, eng.inject_u = self._inject["pre"]
         paths = eng.generate_paths_native()
         self.last_state["paths_pre"] = paths
+        self._set_bridge_rng(eng.seed, off, "bridge_pre")
         K = self.regression_function.get_degree()
         comp = self._comp
         jobs = []
@@ -428,6 +437,11 @@ class SimulationController:
             if R:
                 b1 = self._reg_coeff_base[p_i]
                 p.regression_coeffs = torch.from_numpy(mirror[b1:b1 + R * S * K].reshape(R, S, K).copy())
+
+    def _set_bridge_rng(self, seed: int, path_offset: int, inject_key: str):
+        """Brownian-bridge barrier events draw their uniforms inside the book / LSM kernels (mcx_book_set_bridge_rng)"""
+        if any(getattr(p, "use_brownian_bridge", False) for p in self.products):
+            self.backend.book_set_bridge_rng(self.book, int(seed), int(path_offset), self._inject.get(inject_key))
 
     def _register_regression_atoms(self):
         """atoms the LSM needs must exist before the book is uploaded"""
@@ -573,6 +587,7 @@ class SimulationController:
         if "main" in self._inject:
             self._main_engine.inject_z, self._main_engine.inject_u = self._inject["main"]
         self._fused = self._build_fused() if (self.allow_fused and self._mc_products) else None
+        self._set_bridge_rng(self._main_engine.seed, self._main_engine.path_offset, "bridge_main")     # after the pre-simulation's
         be.synchronize()
 
     def _build_fused(self):

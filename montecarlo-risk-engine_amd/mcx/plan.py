@@ -103,6 +103,7 @@ class BookCompiler:
         self._atom_key: dict = {}
         self.terms: list[tuple] = []
         self.events: list[tuple] = []
+        self.coeff_init: dict[int, float] = {}      # constants parked in the coefficient array (bridge-barrier parameters)
 
     def tidx(self, time) -> int:
         return self.time_to_index[float(time)]
@@ -155,6 +156,8 @@ class BookPlan:
         self.events = np.array(comp.events, dtype=_abi.EVENT_DTYPE) if comp.events else np.zeros(0, dtype=_abi.EVENT_DTYPE)
         self.products = products
         self.coeffs = np.zeros(max(n_coeffs, 1), dtype=np.float64)
+        for off, val in comp.coeff_init.items():
+            self.coeffs[off] = val
         self.n_netting_sets, self.n_expo_rows, self.n_basis = n_netting_sets, n_expo_rows, comp.n_basis
         self.n_state = n_state
         d = _abi.BookDesc()

@@ -3,8 +3,9 @@ products/barrier_option.py:15-125, 298-314).  GPU: one MCX_EV_OPTION event in ag
 every observation date (running max / min in registers), `x_atom` the spot at maturity (include/mcx.h).  The payoff is
 normalised by the numeraire of the FIRST observation date exactly like the reference (:310).
 
-Not built: the Brownian-bridge correction (`set_use_brownian_bridge`, :126-223) — it draws its uniforms from a numpy
-Generator on the host, outside the engine's RNG contract."""
+`set_use_brownian_bridge()` (:126-223) adds the bridge crossing correction (mode 5): one uniform per monitored interval and
+barrier, drawn inside the kernels from the Philox stream (the reference draws them from a numpy Generator on the host; a
+parity run injects those numbers, mcx_book_set_bridge_rng)."""
 from __future__ import annotations
 
 from enum import Enum
@@ -52,7 +53,10 @@ class BarrierOption(Product):
                               for i in range(len(self.modeling_timeline))}
 
     def set_use_brownian_bridge(self):
-        raise NotImplementedError("the Brownian-bridge barrier correction (host numpy RNG) is not part of the GPU path")
+        self.use_brownian_bridge = True
+
+    def _n_extra_coeffs(self) -> int:
+        return 2 if self.use_brownian_bridge else 0
 
     def _cash_events(self, ctx):
         if self.barrier_option_type1 not in _CODE:
@@ -61,8 +65,16 @@ class BarrierOption(Product):
         terms = [(1.0, ctx.atom(AtomicRequest(AtomicRequestType.SPOT), self.get_asset_id(), t)) for t in obs]
         two = self.barrier2 is not None and self.barrier_option_type2 is not None
         types = _CODE[self.barrier_option_type1] + (8 * _CODE[self.barrier_option_type2] if two else 0)
-        aux = (4.0, float(self.barrier1[0]), float(self.barrier2[0]) if two else 0.0, float(types))
+        aux = (5.0 if self.use_brownian_bridge else 4.0, float(self.barrier1[0]), float(self.barrier2[0]) if two else 0.0, float(types))
+        params = ()
+        if self.use_brownian_bridge:
+            from ..models.black_scholes import BlackScholesModel
+            if not isinstance(ctx.model, BlackScholesModel):
+                raise NotImplementedError("the Brownian-bridge correction reads model.get_volatility() of a single-asset Black-Scholes model")
+            sigma = ctx.model._pf(1)
+            # crossing probability exp(-2 ln(S_k/B) ln(S_k+1/B) / (sigma^2 * maturity / n_observations))   (barrier_option.py:146)
+            params = (-2.0 / (sigma * sigma * (self._T / len(obs))), float(ctx.current_product))
         sign = 1.0 if self.option_type == OptionType.CALL else -1.0
         # the maturity spot is the LAST monitored value (paths[:, -1], :70): read it at the last observation date
         return [CashEvent(_abi.EV_OPTION, self._T, terms, strike=self._K, sign=sign, aux=aux, x_asset=self.get_asset_id(),
-                          x_time=obs[-1], num_time=obs[len(self.product_timeline) - 1])]
+                          x_time=obs[-1], num_time=obs[len(self.product_timeline) - 1], coeff_params=params)]

@@ -49,6 +49,7 @@ class CashEvent:
     aux: tuple = (0.0, 0.0, 0.0, 0.0)   # OPTION: basket aggregation mode + control-variate constant (include/mcx.h)
     num_time: float | None = None       # date whose numeraire normalises the event (default: the event's own date)
     x_time: float | None = None         # date at which x_asset's spot is read (default: the event's own date)
+    coeff_params: tuple = ()            # constants the event reads from the coefficient array at its coeff_off (bridge barrier)
 
 
 class Product:
@@ -109,6 +110,10 @@ class Product:
         self.regression_coeffs = torch.zeros(
             (len(self.regression_timeline), self.get_num_states(), regression_function.get_degree()),
             dtype=FLOAT, device=device)
+
+    def _n_extra_coeffs(self) -> int:
+        """doubles this product parks in the coefficient array besides regression coefficients"""
+        return 0
 
     def supports_analytic_pv(self, model) -> bool:
         return False

@@ -250,6 +250,13 @@ def mixed_book_multi():
     return ns, model, RiskMetrics([CVAMetric("cp", 0.4), EPEMetric()], exposure_timeline=np.linspace(0.0, horizon, 12))
 
 
+def barrier_bridge():
+    ns, model, rm = barrier()
+    for n in ns:
+        n.products[0].set_use_brownian_bridge()
+    return ns, model, rm
+
+
 def bs_european_exposure():
     model = BlackScholesModel(0, 100.0, 0.03, 0.25)
     c = EuropeanOption(Equity(), 1.0, 95.0, OptionType.CALL); c.name = "call"
@@ -286,6 +293,7 @@ CASES = {
     "binary_asian_euler": (binary_asian, 0, 1024, 3, E, False),
     "barrier": (barrier, 0, 2048, 2, A, False),
     "barrier_euler": (barrier, 0, 2048, 3, E, False),
+    "barrier_bridge": (barrier_bridge, 0, 2048, 2, A, False),
     "flexicall": (flexicall, 2048, 1024, 1, A, False),
     "mixed_book_multi": (mixed_book_multi, 128, 128, 1, E, False),
     # sensitivities through the LSM regression; the fixtures hold only the reference gradients, draws = the base case's
@@ -313,6 +321,15 @@ def make_controller(name, backend, inject=True, fused=True):
             u = backend.from_numpy(np.ascontiguousarray(gd[key_u][:, :, 0])) if key_u in gd.files else None
             return z, u
         sc._inject["main"] = prep("z_main", "u_main")
+        bridge = {}
+        for k in [k for k in g.files if k.startswith("bridge_u_")]:       # recorded numpy uniforms [calls][N][intervals]
+            calls = g[k]
+            rows = np.zeros((2 * calls.shape[2], calls.shape[1]))
+            for bi in range(calls.shape[0]):
+                rows[bi::2] = calls[bi].T
+            bridge[int(k.rsplit("_", 1)[1])] = backend.from_numpy(rows)
+        if bridge:
+            sc._inject["bridge_main"] = bridge
         if "z_pre" in gd.files:
             sc._inject["pre"] = prep("z_pre", "u_pre")
     return sc, g

@@ -550,6 +550,38 @@ def case_mixed_book_multi():
     return ns, model, RiskMetrics([CVAMetric("cp", 0.4), EPEMetric()], exposure_timeline=np.linspace(0.0, horizon, 12))
 
 
+class _RecordingRng:
+    """wraps a product's numpy Generator and keeps every uniform block it hands out (Brownian-bridge draws)"""
+
+    def __init__(self, rng):
+        self.rng, self.calls = rng, []
+
+    def uniform(self, *a, **k):
+        u = self.rng.uniform(*a, **k)
+        self.calls.append(np.array(u, dtype=np.float64))
+        return u
+
+
+def case_barrier_bridge():
+    """barrier options with the Brownian-bridge crossing correction (barrier_option.py:126-223); the uniforms of the products'
+    numpy Generators are recorded and injected on the other side"""
+    model = BlackScholesModel(0, 100.0, 0.03, 0.25)
+    B = BarrierOptionType
+    prods = [BarrierOption(0.0, 1.0, 100.0, 6, OptionType.CALL, 125.0, B.UPANDOUT),
+             BarrierOption(0.0, 1.0, 105.0, 6, OptionType.PUT, 90.0, B.DOWNANDIN),
+             BarrierOption(0.2, 1.2, 95.0, 5, OptionType.CALL, 85.0, B.DOWNANDOUT, 130.0, B.UPANDOUT),
+             BarrierOption(0.0, 0.8, 100.0, 5, OptionType.PUT, 110.0, B.UPANDIN, 80.0, B.DOWNANDOUT)]
+    for k, p in enumerate(prods):
+        p.name = f"b{k}"
+        p.set_use_brownian_bridge()
+        p.rng = _RecordingRng(p.rng)
+    return [NettingSet(name=p.name, products=[p]) for p in prods], model, RiskMetrics([PVMetric()])
+
+
+def _bridge_extra(sc, model):
+    return {f"bridge_u_{i}": np.stack(p.rng.calls, axis=0) for i, p in enumerate(sc.products) if isinstance(getattr(p, "rng", None), _RecordingRng)}
+
+
 def case_bs_european_exposure():
     """analytic Black-Scholes exposure path (european_option.py:123-145, controller.py:430-437): no regression"""
     model = BlackScholesModel(0, 100.0, 0.03, 0.25)
@@ -563,7 +595,7 @@ def case_bs_european_exposure():
 def main():
     torch.set_num_threads(4)
     if len(sys.argv) > 1 and sys.argv[1] == "new":
-        run_controller_case("mixed_book_multi", case_mixed_book_multi, 128, 128, 1, SimulationScheme.EULER)
+        run_controller_case("barrier_bridge", case_barrier_bridge, 0, 2048, 2, SimulationScheme.ANALYTICAL, extra=_bridge_extra)
         return
     gen_steps()
     gen_paths_mc4()
@@ -598,6 +630,7 @@ def main():
     run_controller_case("barrier_euler", case_barrier, 0, 2048, 3, E)
     run_controller_case("flexicall", case_flexicall, 2048, 1024, 1, A)
     run_controller_case("mixed_book_multi", case_mixed_book_multi, 128, 128, 1, E)
+    run_controller_case("barrier_bridge", case_barrier_bridge, 0, 2048, 2, A, extra=_bridge_extra)
 
 
 if __name__ == "__main__":

@@ -29,6 +29,7 @@ def load_oracle() -> C.CDLL:
     lib = C.CDLL(build_oracle())
     lib.orc_philox4x32_10.restype = None
     lib.orc_draw.restype = None
+    lib.orc_set_bridge_rng.restype = None
     return lib
 
 
@@ -84,6 +85,17 @@ class OracleBackend:
     def book_set_coeffs(self, book, offset, values):
         v = np.ascontiguousarray(values, dtype=np.float64).reshape(-1)
         book.plan.coeffs[offset:offset + v.size] = v
+
+    def book_set_bridge_rng(self, book, seed, path_offset, inject=None):
+        table, ld = None, 0
+        if inject:
+            arr = (C.c_void_p * book.plan.desc.n_products)()
+            for p_i, t in inject.items():
+                arr[p_i] = t.data_ptr()
+                ld = t.shape[1]
+            table = arr
+            self._keep_bridge = (arr, dict(inject))
+        self.lib.orc_set_bridge_rng(C.c_uint64(seed), C.c_uint64(path_offset), table, C.c_int64(ld))
 
     def eval_book(self, book, paths):
         plan = book.plan
