@@ -17,10 +17,12 @@ rank 1, reference test `tests/pytests/test_cva_large_netting_set_aad_vs_fd.py` â
 COMMON RANDOM NUMBERS: the Philox counters (or the injected draws) are identical in the bumped runs, so the difference
 quotient converges to the same pathwise derivative the reference's tape returns (including the dependence of the regression
 coefficients on the parameters through the pre-simulation), with O(h^2) truncation and no sampling noise.  It costs 2P + 1
-passes of the millisecond-scale hot path instead of one tangent pass; a forward-mode kernel for this path is the next step."""
+passes of the millisecond-scale hot path and serves what the forward-mode kernels do not cover (exercise products, PFE,
+collateral, analytic exposures, non-Euler schemes)."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 import time
 
@@ -180,19 +182,33 @@ class _NoTangentForm(Exception):
     pass
 
 
-def _host_descriptors(sc):
+def _host_descriptors(sc, model=None):
     """every host-computed number the kernels consume (slot parameters, initial state, per-step tables, atom coefficients) of a
-    controller, WITHOUT touching the GPU"""
-    from .plan import BookPlan
-    sc._compile()
-    if sc.requires_regression:
-        sc._register_regression_atoms()
-    book = BookPlan(sc._comp, *sc._plan_args)
-    sim = SimPlan(sc.model, sc.simulation_timeline.numpy(), sc.simulation_scheme, sc.num_steps)
-    slots = np.array([[sim.desc.slots[s].p[j] for j in range(_abi.SLOT_NPARAM)] for s in range(sim.n_slots)])
-    atoms = np.stack([book.atoms[k].astype(np.float64) for k in ("a", "d", "b", "c0", "c1")], axis=1) if len(book.atoms) else np.zeros((0, 5))
-    shape = (tuple(book.atoms["t_idx"]), tuple(book.atoms["col"]), len(book.terms), len(book.events), sim.n_steps)
-    return dict(slots=slots, init=sim.init_state.copy(), aux=sim.aux.copy(), atoms=atoms), shape
+    COMPILED controller, re-evaluated under `model` (default: its own) WITHOUT touching the GPU.  Only the model-dependent
+    numbers are recomputed: the per-step tables of the existing sub-step schedule and the closed-form coefficients of the
+    existing atoms (requests, events and terms do not depend on the model parameters)."""
+    model = sc.model if model is None else model
+    sim, comp = sc.sim_plan, sc._comp
+    specs = model._slots()
+    slots = np.zeros((sim.n_slots, _abi.SLOT_NPARAM))
+    for s, sp in enumerate(specs):
+        slots[s, :len(sp.params)] = sp.params
+    aux = np.zeros_like(sim.aux)
+    for k in range(sim.n_steps):
+        for s, vals in enumerate(model._step_aux(sim.scheme, float(sim.steps["t1"][k]), float(sim.steps["dt"][k]))):
+            aux[k, s, :len(vals)] = vals
+    atoms = np.zeros((len(comp.atoms), 5))
+    cols = []
+    for q, src in enumerate(comp.atom_src):
+        if src is None:
+            atoms[q, 0] = comp.atoms[q][2]
+            cols.append(-1)
+            continue
+        co = model._atom(*src)
+        atoms[q] = (co.a, co.d, co.b, co.c0, co.c1)
+        cols.append(-1 if co.col is None else co.col)
+    shape = (tuple(cols), tuple(sp.kind for sp in specs))
+    return dict(slots=slots, init=np.array(model._initial_state(), dtype=np.float64), aux=aux, atoms=atoms), shape
 
 
 def _solve_dual(mom: np.ndarray, K: int, shift: float, scale: float, degenerate: bool, n_par: int):
@@ -258,26 +274,33 @@ def run_with_tangent_book(sc):
     P = len(theta)
     smoothing = getattr(sc.model, "perform_smoothing", False)
 
-    def bumped(j, value):
-        m = copy.deepcopy(sc.model)
-        m.perform_smoothing = smoothing
-        _set_param(m, j, value)
-        return _clone_controller(sc, m, False)
-
     # derivative of every descriptor number (closed forms evaluated in float64 on the host): 4-point central differences with
     # a wide step â€” truncation O(h^4) ~ 1e-12, rounding eps/h ~ 1e-13 relative.  (CIR++ sensitivities are small residuals of
     # large cancelling terms: a 2-point formula with h = 1e-6 left 1e-5 relative noise on d CVA / d sigma_cir.)
-    d0, shape0 = _host_descriptors(_clone_controller(sc, copy.deepcopy(sc.model), False))
+    d0, shape0 = _host_descriptors(base)                 # `base` is compiled: its sub-step schedule and atoms are re-evaluated
+
+    def bumped_model(j, value):
+        m = copy.deepcopy(sc.model)
+        m.perform_smoothing = smoothing
+        _set_param(m, j, value)
+        return m
+
     dd = {k: np.zeros(v.shape + (P,)) for k, v in d0.items()}
+    four_point = os.environ.get("MCX_DESCRIPTOR_FD", "4") == "4"
     for j in range(P):
-        h = 1e-3 * max(abs(theta[j]), 1e-2)
+        h = (1e-3 if four_point else 1e-4) * max(abs(theta[j]), 1e-2)
         ev = {}
-        for mult in (1, -1, 2, -2):
-            ev[mult], shp = _host_descriptors(bumped(j, theta[j] + mult * h))
+        for mult in ((1, -1, 2, -2) if four_point else (1, -1)):
+            ev[mult], shp = _host_descriptors(base, bumped_model(j, theta[j] + mult * h))
             if shp != shape0:
                 raise _NoTangentForm("descriptor structure depends on the parameters")
         for k in dd:
-            dd[k][..., j] = (8.0 * (ev[1][k] - ev[-1][k]) - (ev[2][k] - ev[-2][k])) / (12.0 * h)
+            if four_point:
+                dd[k][..., j] = (8.0 * (ev[1][k] - ev[-1][k]) - (ev[2][k] - ev[-2][k])) / (12.0 * h)
+            else:
+                dd[k][..., j] = (ev[1][k] - ev[-1][k]) / (2.0 * h)
+    t_desc = time.perf_counter() - t0
+    t_pre = t_main = 0.0
     book, sim, K = base.book, base._sim, base.book_plan.n_basis
     n_coeffs = len(base.book_plan.coeffs)
     n_ns, n_metrics = len(sc.netting_sets), len(rm.metrics)
@@ -295,6 +318,7 @@ def run_with_tangent_book(sc):
         dslot, dinit, daux = pad(dd["slots"]), pad(dd["init"]), pad(dd["aux"])
         datoms = be.from_numpy(pad(dd["atoms"]))
         coeffs, dcoeffs = np.zeros(max(n_coeffs, 1)), np.zeros((max(n_coeffs, 1), NP))
+        t1 = time.perf_counter()
         if jobs:
             off, n_pre = shard.split(sc.num_paths_presim)
             paths_pre, dpaths_pre = be.tangent_paths(sim, dslot, dinit, daux, 42 + sc.seed_offset, off, n_pre,
@@ -320,6 +344,9 @@ def run_with_tangent_book(sc):
                     o = base._expo_coeff_base[p_i] + expo_idx * K
                     coeffs[o:o + K], dcoeffs[o:o + K] = c, dc.T
             del paths_pre, dpaths_pre
+        be.synchronize()
+        t2 = time.perf_counter()
+        t_pre += t2 - t1
         off, n_main = shard.split(sc.num_paths_mainsim)
         paths, dpaths = be.tangent_paths(sim, dslot, dinit, daux, 43 + sc.seed_offset, off, n_main,
                                          sc._inject.get("main", (None, None))[0])
@@ -343,8 +370,11 @@ def run_with_tangent_book(sc):
                     for q, j in enumerate(sel):
                         grads[ns_i][m_i][0][j] = mean_of(out[1 + q])
         del paths, dpaths, cfs, expo
+        be.synchronize()
+        t_main += time.perf_counter() - t2
     sc.sim_plan, sc.last_state = base.sim_plan, base.last_state
-    sc.timings = dict(total=time.perf_counter() - t0, tangent=True, forward_mode_passes=(P + NP - 1) // NP)
+    sc.timings = dict(total=time.perf_counter() - t0, tangent=True, forward_mode_passes=(P + NP - 1) // NP,
+                      base_run_and_descriptor_derivatives=t_desc, presim_and_regression=t_pre, main=t_main)
     g = [[[tuple(ev) for ev in grads[ns_i][m_i]] for m_i in range(n_metrics)] for ns_i in range(n_ns)]
     return sc._package([[[tuple(v) for v in evals] for evals in per_metric] for per_metric in res0.results], g, [])
 

@@ -203,6 +203,7 @@ class SimulationController:
         sim_tl = [float(t) for t in self.simulation_timeline]
         K = self.regression_function.get_degree()
         comp = BookCompiler(self.model, sim_tl, K)
+        self._sched_atom_cache = {}          # atom ids belong to ONE compiler: a re-compilation must not reuse the previous ones
         E = len(self.exposure_timeline)
         expo_times = [float(t) for t in self.exposure_timeline]
         want_expo = rm.requires_exposure_profiles()

@@ -100,6 +100,7 @@ class BookCompiler:
         self.time_to_index = {float(t): i for i, t in enumerate(sim_timeline)}
         self.n_basis = n_basis
         self.atoms: list[tuple] = []
+        self.atom_src: list = []                    # (request, asset_id) behind every atom (None: constant) — re-evaluated under bumped models
         self._atom_key: dict = {}
         self.terms: list[tuple] = []
         self.events: list[tuple] = []
@@ -116,6 +117,7 @@ class BookCompiler:
             co = self.model._atom(req, asset_id)
             hit = self._atom_key[key] = len(self.atoms)
             self.atoms.append((ti, -1 if co.col is None else co.col, co.a, co.d, co.b, co.c0, co.c1))
+            self.atom_src.append((req, asset_id))
         return hit
 
     def const_atom(self, value: float) -> int:
@@ -123,6 +125,7 @@ class BookCompiler:
         if key not in self._atom_key:
             self._atom_key[key] = len(self.atoms)
             self.atoms.append((0, -1, float(value), 0.0, 0.0, 0.0, 0.0))
+            self.atom_src.append(None)
         return self._atom_key[key]
 
     def add_terms(self, terms) -> tuple[int, int]:
