@@ -79,7 +79,16 @@ class Model:
             p.requires_grad_(True)
 
     def _pf(self, i: int) -> float:
-        return float(self.model_params[i].detach())
+        """parameter i as a Python float; memoised on the tensor's identity and in-place version counter (the closed-form
+        coefficient code calls this ~10^4 times per compilation)"""
+        t = self.model_params[i]
+        cache = self.__dict__.setdefault("_pf_cache", {})
+        hit = cache.get(i)
+        if hit is not None and hit[0] is t and hit[1] == t._version:
+            return hit[2]
+        v = float(t.detach())
+        cache[i] = (t, t._version, v)
+        return v
 
     def t0(self) -> float:
         return float(self.calibration_date[0])
