@@ -231,6 +231,22 @@ class SimulationController:
                 expo_atom_cache[asset] = hit
             return hit
 
+        expo_arr = np.asarray(expo_times, dtype=np.float64)
+        expo_tmpl_cache: dict = {}
+
+        def expo_template(asset):    # EVENT_DTYPE rows of the exposure events of one asset, product-independent fields filled
+            hit = expo_tmpl_cache.get(asset)
+            if hit is None:
+                hit = np.zeros(E, dtype=_abi.EVENT_DTYPE)
+                at = expo_atoms(asset)
+                hit["t_idx"] = [comp.tidx(t) for t in expo_times]
+                hit["num_atom"] = [a_[0] for a_ in at]
+                hit["x_atom"] = [a_[1] for a_ in at]
+                hit["expo_row"] = np.arange(E)
+                hit["sign"] = 1.0
+                expo_tmpl_cache[asset] = hit
+            return hit
+
         for p_i, p in enumerate(self.products):
             S = p.get_num_states()
             skip = self._can_skip_monte_carlo_for_product(p)
@@ -251,33 +267,46 @@ class SimulationController:
                         comp.coeff_init[co + k_] = float(v_)
                 return comp.add_event(ce.kind, comp.tidx(ce.time), num, x, comp.add_terms(ce.terms), co, -1, ce.strike, ce.sign, ce.aux)
 
-            cf_begin = len(comp.events)
+            cf_begin = comp.n_events
             for ce in cash:
                 emit_cash(ce)
-            cf_end = len(comp.events)
-            ev_begin = len(comp.events)
+            cf_end = comp.n_events
+            ev_begin = comp.n_events
             if not skip:
                 t_start = 0
                 if want_expo:
+                    # exposure events of ALL dates as array blocks, the product's cashflow events spliced in where the reference
+                    # evaluates them: before the first exposure date that is not earlier (controller.py:417-426)
                     analytic = self._can_use_analytic_exposure_for_product(p)
-                    for i, t in enumerate(expo_times):
-                        while t_start < len(pdates) and pdates[t_start] <= t:            # controller.py:417-426
-                            emit_cash(cash[t_start])
-                            t_start += 1
-                        num, x = expo_atoms(p.asset_ids[0])[i]
-                        if analytic:
-                            _s, sig_p, rate_p = p._bs_inputs(self.model)
-                            aux = (sig_p, rate_p, float(p.exercise_date[0]) - t, 0.0)
-                            comp.add_event(_abi.EV_EXPO_BS, comp.tidx(t), num, x, (0, 0), -1, i, p._K, p._sign(), aux)
-                        else:
-                            comp.add_event(_abi.EV_EXPO_POLY, comp.tidx(t), num, x, (0, 0),
-                                           self._expo_coeff_base[p_i] + i * S * K, i)
+                    tmpl = expo_template(p.asset_ids[0])
+                    blk = tmpl.copy()
+                    if analytic:
+                        _s, sig_p, rate_p = p._bs_inputs(self.model)
+                        blk["kind"] = _abi.EV_EXPO_BS
+                        blk["coeff_off"] = -1
+                        blk["strike"], blk["sign"] = p._K, p._sign()
+                        blk["aux"][:, 0], blk["aux"][:, 1] = sig_p, rate_p
+                        blk["aux"][:, 2] = float(p.exercise_date[0]) - expo_arr
+                    else:
+                        blk["kind"] = _abi.EV_EXPO_POLY
+                        blk["coeff_off"] = self._expo_coeff_base[p_i] + np.arange(E, dtype=np.int64) * (S * K)
+                    first = np.searchsorted(expo_arr, np.asarray(pdates), side="left") if pdates else np.zeros(0, dtype=np.int64)
+                    pos = 0
+                    for c_i, f in enumerate(first):
+                        if f >= E:
+                            break                       # paid after the last exposure date: emitted below if cashflows are wanted
+                        if f > pos:
+                            comp.add_event_block(blk[pos:f])
+                            pos = int(f)
+                        emit_cash(cash[c_i])
+                        t_start = c_i + 1
+                    comp.add_event_block(blk[pos:])
                 if want_cfs or not want_expo:
                     while t_start < len(pdates):                                          # controller.py:401-410, 451-461
                         emit_cash(cash[t_start])
                         t_start += 1
                 self._mc_products.append(p_i)
-            ev_end = len(comp.events)
+            ev_end = comp.n_events
             prods[p_i] = (ev_begin, ev_end, cf_begin, cf_end, self.product_to_netting_set_idx[p_i],
                           p.get_initial_state(), S, 0)
         # CVA survival atoms (cva_metric.py:23-46)
@@ -399,33 +428,54 @@ class SimulationController:
             tot += S * n_local
         W = be.zeros(max(tot, 1))
         mirror = np.zeros(len(self.book_plan.coeffs))                 # host image of the coefficients this pass produces
-        max_len = max(len(sched) for _, _, sched, _ in jobs)
+        # products sharing (schedule, explanatory asset, state count) differ only in their ids and offsets: one vectorised
+        # block of the job table per class and step instead of a Python iteration per (product, date)
+        classes: dict = {}
+        for j, (p_i, p, sched, atoms) in enumerate(jobs):
+            classes.setdefault((id(sched), id(atoms), S_of[j]), []).append(j)
+        cls = []
+        for (_, _, S), members in classes.items():
+            _, _, sched, atoms = jobs[members[0]]
+            L = len(sched)
+            lo = np.array([x_range[x][0] for _, x in atoms]); hi = np.array([x_range[x][1] for _, x in atoms])
+            deg = ~(hi > lo)
+            cls.append(dict(S=S, L=L, members=np.array(members),
+                            p_i=np.array([jobs[m][0] for m in members], dtype=np.int32),
+                            w_off=np.array([w_off[m] for m in members], dtype=np.int64),
+                            reg_base=np.array([self._reg_coeff_base[jobs[m][0]] for m in members], dtype=np.int64),
+                            expo_base=np.array([self._expo_coeff_base[jobs[m][0]] for m in members], dtype=np.int64),
+                            r0=[s[1] for s in sched], r1=[s[2] for s in sched],
+                            prod_idx=[-1 if s[3] is None else s[3] for s in sched],
+                            expo_idx=[-1 if s[4] is None else s[4] for s in sched],
+                            num=[a_[0] for a_ in atoms], x=[a_[1] for a_ in atoms], xmin=lo, deg=deg,
+                            shift=np.where(deg, lo, 0.5 * (lo + hi)), scale=np.where(deg, 1.0, 2.0 / np.where(deg, 1.0, hi - lo))))
+        max_len = max(cl["L"] for cl in cls)
         for r in range(max_len):
-            by_S: dict[int, list[int]] = {}
-            for j, (_, _, sched, _) in enumerate(jobs):
-                if r < len(sched):
-                    by_S.setdefault(S_of[j], []).append(j)
-            for S, members in sorted(by_S.items()):
-                arr = np.zeros(len(members), dtype=_abi.LSM_JOB_DTYPE)
-                xmin = np.zeros(len(members)); deg = np.zeros(len(members), dtype=bool)
-                targets = []                                          # (row in arr, coefficient offset)
-                for q, j in enumerate(members):
-                    p_i, p, sched, atoms = jobs[j]
-                    (t_reg, r0, r1, prod_idx, expo_idx), (num, x) = sched[r], atoms[r]
-                    lo, hi = x_range[x]
-                    degenerate = not (hi > lo)
-                    arr[q] = (p_i, r0, r1, num, x, 0, w_off[j], 0.5 * (lo + hi) if not degenerate else lo,
-                              2.0 / (hi - lo) if not degenerate else 1.0)
-                    xmin[q], deg[q] = lo, degenerate
-                    if prod_idx is not None:
-                        targets.append((q, self._reg_coeff_base[p_i] + prod_idx * S * K))
-                    if expo_idx is not None:
-                        targets.append((q, self._expo_coeff_base[p_i] + expo_idx * S * K))
+            for S in sorted({cl["S"] for cl in cls if cl["L"] > r}):
+                blocks, xmin_b, deg_b, t_rows, t_offs, row0 = [], [], [], [], [], 0
+                for cl in cls:
+                    if cl["S"] != S or cl["L"] <= r:
+                        continue
+                    n_m = len(cl["members"])
+                    arr = np.zeros(n_m, dtype=_abi.LSM_JOB_DTYPE)
+                    arr["product"], arr["w_offset"] = cl["p_i"], cl["w_off"]
+                    arr["roll_begin"], arr["roll_end"], arr["num_atom"], arr["x_atom"] = cl["r0"][r], cl["r1"][r], cl["num"][r], cl["x"][r]
+                    arr["shift"], arr["scale"] = cl["shift"][r], cl["scale"][r]
+                    blocks.append(arr)
+                    xmin_b.append(np.full(n_m, cl["xmin"][r])); deg_b.append(np.full(n_m, cl["deg"][r]))
+                    rows = row0 + np.arange(n_m)
+                    if cl["prod_idx"][r] >= 0:
+                        t_rows.append(rows); t_offs.append(cl["reg_base"] + cl["prod_idx"][r] * S * K)
+                    if cl["expo_idx"][r] >= 0:
+                        t_rows.append(rows); t_offs.append(cl["expo_base"] + cl["expo_idx"][r] * S * K)
+                    row0 += n_m
+                arr = np.concatenate(blocks)
                 mom = be.lsm_step_batch(self.book, arr, S, paths, W, n_local, flags=lsm_flags)
                 mom = shard.all_reduce_np(mom)
-                coeffs = solve_normal_equations_batch(mom, K, S, arr["shift"], arr["scale"], deg, xmin).reshape(len(members), S * K)
-                if targets:
-                    rows = np.array([t[0] for t in targets]); offs = np.array([t[1] for t in targets], dtype=np.int64)
+                coeffs = solve_normal_equations_batch(mom, K, S, arr["shift"], arr["scale"], np.concatenate(deg_b),
+                                                      np.concatenate(xmin_b)).reshape(len(arr), S * K)
+                if t_rows:
+                    rows, offs = np.concatenate(t_rows), np.concatenate(t_offs).astype(np.int64)
                     vals = coeffs[rows]
                     be.book_set_coeffs_batch(self.book, offs, vals)
                     mirror[offs[:, None] + np.arange(S * K)[None, :]] = vals

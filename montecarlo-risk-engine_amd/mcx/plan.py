@@ -103,7 +103,8 @@ class BookCompiler:
         self.atom_src: list = []                    # (request, asset_id) behind every atom (None: constant) — re-evaluated under bumped models
         self._atom_key: dict = {}
         self.terms: list[tuple] = []
-        self.events: list[tuple] = []
+        self.events: list = []                      # tuples and EVENT_DTYPE blocks, in order
+        self.n_events = 0
         self.coeff_init: dict[int, float] = {}      # constants parked in the coefficient array (bridge-barrier parameters)
 
     def tidx(self, time) -> int:
@@ -146,7 +147,30 @@ class BookCompiler:
                   aux=(0.0, 0.0, 0.0, 0.0)) -> int:
         self.events.append((kind, t_idx, num_atom, x_atom, term_range[0], term_range[1], coeff_off, expo_row,
                             float(strike), float(sign), tuple(aux)))
-        return len(self.events) - 1
+        self.n_events += 1
+        return self.n_events - 1
+
+    def add_event_block(self, block: np.ndarray) -> None:
+        """a run of events as one EVENT_DTYPE array (the per-(product, exposure date) events of big books: 10^6 of them)"""
+        if len(block):
+            self.events.append(block)
+            self.n_events += len(block)
+
+    def events_array(self) -> np.ndarray:
+        if not self.events:
+            return np.zeros(0, dtype=_abi.EVENT_DTYPE)
+        parts, run = [], []
+        for e in self.events:
+            if isinstance(e, np.ndarray):
+                if run:
+                    parts.append(np.array(run, dtype=_abi.EVENT_DTYPE))
+                    run = []
+                parts.append(e)
+            else:
+                run.append(e)
+        if run:
+            parts.append(np.array(run, dtype=_abi.EVENT_DTYPE))
+        return np.ascontiguousarray(np.concatenate(parts)) if len(parts) > 1 else np.ascontiguousarray(parts[0])
 
 
 class BookPlan:
@@ -156,7 +180,7 @@ class BookPlan:
                  want_cfs: bool, want_expo: bool, n_state: int):
         self.atoms = np.array(comp.atoms, dtype=_abi.ATOM_DTYPE) if comp.atoms else np.zeros(0, dtype=_abi.ATOM_DTYPE)
         self.terms = np.array(comp.terms, dtype=_abi.TERM_DTYPE) if comp.terms else np.zeros(0, dtype=_abi.TERM_DTYPE)
-        self.events = np.array(comp.events, dtype=_abi.EVENT_DTYPE) if comp.events else np.zeros(0, dtype=_abi.EVENT_DTYPE)
+        self.events = comp.events_array()
         self.products = products
         self.coeffs = np.zeros(max(n_coeffs, 1), dtype=np.float64)
         for off, val in comp.coeff_init.items():
