@@ -277,6 +277,9 @@ int  mcx_resolve_atoms(mcx_handle* h, const mcx_book* book, const int32_t* h_ato
 int  mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_book* book, const mcx_fused_desc* desc, mcx_fused** out);
 void mcx_fused_destroy(mcx_fused* f);
 int  mcx_fused_num_records(const mcx_fused* f);
+/* 1 when every timeline date of the program compiled to a straight-line record (the lean kernel: the one-launch plan is then
+ * the fastest), 0 when some dates run the generic interpreter (K1 + mcx_fused_eval_paths is usually faster) */
+int  mcx_fused_is_straight_line(const mcx_fused* f);
 int  mcx_fused_run(mcx_handle* h, const mcx_fused* f, uint64_t seed, uint64_t path_offset, int64_t n_paths,
                    double* d_paths, int64_t ld, double* d_cfs, double* d_expo, int64_t ld_out,
                    const double* d_inject_z, const double* d_inject_u, mcx_acc* h_out, void* stream);

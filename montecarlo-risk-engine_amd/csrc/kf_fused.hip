@@ -877,6 +877,11 @@ static int fused_run_impl(mcx_handle* h, const mcx_fused* f, bool simulate, uint
     return 0;
 }
 
+extern "C" int mcx_fused_is_straight_line(const mcx_fused* f)
+{
+    return (f && f->npf < 0) ? 1 : 0;
+}
+
 extern "C" int mcx_fused_run(mcx_handle* h, const mcx_fused* f, uint64_t seed, uint64_t path_offset, int64_t n_paths,
                              double* d_paths, int64_t ld, double* d_cfs, double* d_expo, int64_t ld_out,
                              const double* d_inject_z, const double* d_inject_u, mcx_acc* h_out, void* stream)

@@ -22,7 +22,7 @@ _EXPORTS = [
     "mcx_sim_create", "mcx_sim_destroy", "mcx_generate_paths",
     "mcx_book_create", "mcx_book_destroy", "mcx_book_set_coeffs", "mcx_eval_book", "mcx_resolve_atoms",
     "mcx_lsm_stats", "mcx_lsm_step", "mcx_lsm_step_batch", "mcx_book_set_coeffs_batch", "mcx_book_set_bridge_rng",
-    "mcx_tangent_paths", "mcx_tangent_lsm", "mcx_tangent_eval", "mcx_tangent_cva", "mcx_tangent_profiles",
+    "mcx_fused_is_straight_line", "mcx_tangent_paths", "mcx_tangent_lsm", "mcx_tangent_eval", "mcx_tangent_cva", "mcx_tangent_profiles",
     "mcx_tangent_european", "mcx_fused_create", "mcx_fused_destroy", "mcx_fused_num_records", "mcx_fused_run", "mcx_fused_eval_paths",
     "mcx_reduce_vector", "mcx_reduce_profiles", "mcx_reduce_cva", "mcx_unsecured", "mcx_select_hist",
 ]
@@ -43,6 +43,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.mcx_book_destroy.restype = None
     lib.mcx_fused_destroy.restype = None
     lib.mcx_fused_num_records.argtypes = [C.c_void_p]
+    lib.mcx_fused_is_straight_line.argtypes = [C.c_void_p]
     if lib.mcx_abi_version() != _abi.ABI_VERSION:
         raise RuntimeError("libmcx_hip.so ABI version mismatch")
     return lib
@@ -196,6 +197,9 @@ class HipBackend:
             self.h, fused.ptr, C.c_uint64(seed), C.c_uint64(path_offset), C.c_int64(n_paths), dp(paths), C.c_int64(n_paths),
             dp(cfs), dp(expo), C.c_int64(n_paths), dp(inject_z), dp(inject_u), _abi.ptr(out), self._stream()), "mcx_fused_run")
         return out
+
+    def fused_is_straight_line(self, f) -> bool:
+        return bool(self.lib.mcx_fused_is_straight_line(f.ptr))
 
     def fused_eval_paths(self, fused, paths: torch.Tensor, cfs=None, expo=None) -> np.ndarray:
         out = np.zeros(fused.plan.n_records, dtype=_abi.ACC_DTYPE)

@@ -99,8 +99,9 @@ class SimulationController:
         self.reference_float32_cf_cache = True
         self.allow_fused = True      # fused event/metric program (csrc/kf_fused.hip) when the book is fusable
         # main-pass execution plan when fusable: "semi" = K1 writes the paths tensor, ONE kernel evaluates book + metrics
-        # from it; "fused" = a single launch, nothing materialised; (None/unfusable: K1, K2, K4 as separate launches)
-        self.main_plan = "semi"
+        # from it; "fused" = a single launch, nothing materialised; "auto" = fused when every date of the book compiled to a
+        # straight-line record (the lean kernel), semi otherwise; (None/unfusable: K1, K2, K4 as separate launches)
+        self.main_plan = "auto"
         self.materialize = False     # also write paths / cashflows / exposures in the fused pass (inspection, tests)
         self.batch_lsm = True        # product-batched LSM pre-simulation (one launch per backward step of the whole book)
         self.forward_mode = True     # differentiate=True: dual-number pass where it exists, bump-and-revalue otherwise
@@ -675,7 +676,10 @@ class SimulationController:
     def _fused_pass(self, paths_out=None):
         be, f, eng = self.backend, self._fused, self._main_engine
         n = eng.num_paths
-        semi = self.main_plan == "semi" and hasattr(be, "fused_eval_paths")
+        plan = self.main_plan
+        if plan == "auto":
+            plan = "fused" if (hasattr(be, "fused_is_straight_line") and be.fused_is_straight_line(f)) else "semi"
+        semi = plan == "semi" and hasattr(be, "fused_eval_paths")
         need_expo = self._fused_needs_expo or self.materialize
         paths = (paths_out if paths_out is not None else be.empty(self.sim_plan.n_dates, self.sim_plan.n_state, n)) \
             if (self.materialize or paths_out is not None or semi) else None
