@@ -87,9 +87,7 @@ __device__ __forceinline__ double f_atom(const FAtom& a, const double (&reg)[NRE
     // the program lives in LDS, so its fields arrive in VGPRs; the CONTROL fields are made wave-uniform SGPRs
     // (v_readfirstlane) so that selects / branches are scalar instead of exec-masked divergent code
     const int r = RFL(a.reg), fl = RFL(a.pad);          // pad: bit0 = has exp term, bit1 = has affine term
-    double x = 0.0;
-#pragma unroll
-    for (int q = 0; q < NREG; ++q) x = (r == q) ? reg[q] : x;
+    const double x = r >= 0 ? reg[r] : 0.0;             // uniform dynamic index -> M0-relative VGPR read (v_movrels)
     double v = (fl & 2) ? fma(a.d, x, a.a) : 0.0;
     if (fl & 1) v = fma(a.b, mcx_exp(fma(a.c1, x, a.c0)), v);
     return v;
