@@ -256,7 +256,8 @@ def run_with_tangent_book(sc):
     rm = sc.risk_metrics
     if sc.simulation_scheme.name != "EULER" or any(ns.is_collateralized() for ns in sc.netting_sets):
         raise _NoTangentForm("scheme / collateral")
-    if any(m.metric_type not in (MetricType.PV, MetricType.CVA, MetricType.EPE, MetricType.ENE) or not m._native for m in rm.metrics):
+    if any(m.metric_type not in (MetricType.PV, MetricType.CVA, MetricType.EPE, MetricType.ENE, MetricType.CE, MetricType.EEPE)
+           or not m._native for m in rm.metrics):
         raise _NoTangentForm("metric")
     if any(p.get_num_states() != 1 for p in sc.products) or len(sc.products) > 64:
         raise _NoTangentForm("products")
@@ -357,13 +358,18 @@ def run_with_tangent_book(sc):
                 if m.metric_type == MetricType.PV:
                     for q, j in enumerate(sel):
                         grads[ns_i][m_i][0][j] = mean_of(cfs[1 + q, ns_i])
-                elif m.metric_type in (MetricType.EPE, MetricType.ENE):
+                elif m.metric_type in (MetricType.EPE, MetricType.ENE, MetricType.CE, MetricType.EEPE):
                     if prof is None:            # [dates][2][NP] sums of 1[u>0] du / 1[u<0] du over all ranks
                         prof = shard.all_reduce_np(be.tangent_profiles(rows, ns.threshold, expo, ns_i)) / float(sc.num_paths_mainsim)
-                    side = 0 if m.metric_type == MetricType.EPE else 1
-                    for e_i in range(n_eval[m_i]):
-                        for q, j in enumerate(sel):
-                            grads[ns_i][m_i][e_i][j] = float(prof[e_i, side, q])
+                    for q, j in enumerate(sel):
+                        if m.metric_type == MetricType.CE:           # positive part of the first exposure date (ce_metric.py)
+                            grads[ns_i][m_i][0][j] = float(prof[0, 0, q])
+                        elif m.metric_type == MetricType.EEPE:       # plain time average of the EE profile (eepe_metric.py)
+                            grads[ns_i][m_i][0][j] = float(prof[:, 0, q].mean())
+                        else:
+                            side = 0 if m.metric_type == MetricType.EPE else 1
+                            for e_i in range(n_eval[m_i]):
+                                grads[ns_i][m_i][e_i][j] = float(prof[e_i, side, q])
                 elif not (ns.counterparty_id is not None and m.counterparty_id != ns.counterparty_id):
                     surv, cond = base._cva_atoms[m_i]
                     out = be.tangent_cva(book, datoms, rows, surv, cond, ns.threshold, m.recovery_rate, expo, ns_i, paths, dpaths)

@@ -273,13 +273,15 @@ def test_forward_mode_cva_against_reference_autograd_and_bumps(hip):
     out = {}
     for fwd in (True, False):
         ns, model, _ = cases.irs_cva()
-        rm = cases.RiskMetrics([cases.CVAMetric("cp", 0.4), cases.PVMetric()], exposure_timeline=np.arange(11) * 0.25)
+        rm = cases.RiskMetrics([cases.CVAMetric("cp", 0.4), cases.PVMetric(), cases.EEPEMetric(), cases.CEMetric(), cases.ENEMetric()],
+                               exposure_timeline=np.arange(11) * 0.25)
         sc = cases.SimulationController(ns, model, rm, 8192, 4096, 3, cases.E, differentiate=True, backend=hip)
         sc.forward_mode = fwd
         r = sc.run_simulation()
         assert bool(sc.timings.get("tangent")) == fwd
-        out[fwd] = (np.array(r.derivatives[0][0][0]), np.array(r.derivatives[0][1][0]), np.array(r.results[0][0]))
-    for k in (0, 1):
+        out[fwd] = (np.array(r.derivatives[0][0][0]), np.array(r.derivatives[0][1][0]), np.array(r.results[0][0]),
+                    np.array(r.derivatives[0][2][0]), np.array(r.derivatives[0][3][0]), np.array(r.derivatives[0][4][3]))
+    for k in (0, 1, 3, 4, 5):
         scale = np.abs(out[False][k]).max()
         assert np.allclose(out[True][k], out[False][k], rtol=2e-5, atol=2e-6 * scale), (k, out[True][k], out[False][k])
     assert np.allclose(out[True][2], out[False][2], rtol=1e-12)
