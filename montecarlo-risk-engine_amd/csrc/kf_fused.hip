@@ -695,13 +695,14 @@ extern "C" int mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_boo
 
     // straight-line records for dates of the linear-book shape (FastDate); such dates need no interpreted chunk
     std::vector<FastDate> fast(T);
+    const bool fast_dates_enabled = d->n_netting_sets == 1 && getenv("MCX_NO_FAST_DATES") == nullptr;     // (env: A/B timing knob)
     for (int t = 0; t < T; ++t) {
         FastDate fd;
         memset(&fd, 0, sizeof(fd));
         fd.ni_reg = fd.lin_reg = fd.x_reg = fd.s_reg = fd.c_reg = -1;
         fd.coeff_off0 = fd.coeff_off1 = -1; fd.rec_profile = -1;
         for (int j = 0; j < 4; ++j) fd.t_reg[j] = -1;
-        bool okf = d->n_netting_sets == 1 && getenv("MCX_NO_FAST_DATES") == nullptr;
+        bool okf = fast_dates_enabled;
         const FAtom* num = nullptr;
         int n_expo = 0;
         for (const FEvent& e : by_date[t]) {
