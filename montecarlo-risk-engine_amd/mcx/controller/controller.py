@@ -752,7 +752,9 @@ class SimulationController:
             logger.info("Simulation completed for %d netting set(s) and %d product(s): preprocessing=%.6fs "
                         "fused_main_pass=%.6fs total=%.6fs", len(self.netting_sets), len(self.products), t1 - t0, t4 - t1, t4 - t0)
             return self._package(results, [], [])
-        paths = self._main_engine.generate_paths_native()
+        # a book valued entirely by closed forms (PVMetric(ANALYTICAL)) needs no paths at all
+        need_paths = bool(self._mc_products) or not all(m._native for m in self.risk_metrics.metrics)
+        paths = self._main_engine.generate_paths_native() if need_paths else None
         be.synchronize()
         t2 = time.perf_counter()
         cfs, expo = be.eval_book(self.book, paths) if self._mc_products else (None, None)
