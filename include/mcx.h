@@ -332,10 +332,12 @@ int  mcx_tangent_eval(mcx_handle* h, const mcx_book* book, const double* d_datom
  * expo_tangent_stride = doubles between consecutive tangent images (n_ns * n_rows * ld) */
 /* EPE / ENE profile tangents of one netting set: h_out [n_dates_metric][2][NP] = sum over the local paths of 1[u > 0] du and of
  * 1[u < 0] du, u = the thresholded exposure (the caller divides by the global path count) */
-int  mcx_tangent_profiles(mcx_handle* h, const int32_t* h_rows, int32_t n_dates_metric, double threshold, const double* d_expo_ns,
+int  mcx_tangent_profiles(mcx_handle* h, const int32_t* h_rows, const int32_t* h_delayed /* nullable */, int32_t collateralized,
+                          int32_t n_dates_metric, double threshold, const double* d_expo_ns,
                           int64_t expo_tangent_stride, int64_t n_paths, int64_t ld, double* h_out, void* stream);
 int  mcx_tangent_cva(mcx_handle* h, const mcx_book* book, const double* d_datoms, const int32_t* h_rows, const int32_t* h_surv,
-                     const int32_t* h_cond, int32_t n_dates_metric, double threshold, double recovery, const double* d_expo_ns,
+                     const int32_t* h_cond, const int32_t* h_delayed /* nullable: rows at t - MPoR */, int32_t collateralized,
+                     int32_t n_dates_metric, double threshold, double recovery, const double* d_expo_ns,
                      int64_t expo_tangent_stride, const double* d_paths, const double* d_dpaths, int64_t n_paths, int64_t ld,
                      int32_t n_dates, double* d_out, void* stream);
 

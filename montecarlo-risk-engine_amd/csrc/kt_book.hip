@@ -309,16 +309,47 @@ __global__ __launch_bounds__(MCX_BLOCK) void kt_eval(const KTEArgs a)
 }
 
 // ---- CVA with tangents ------------------------------------------------------------------------------------------------------
+// unsecured exposure of one netting set at metric date m with tangents (netting_set.py:48-72, 156-184; mcx_unsecured_desc):
+//   not collateralised: thr(E[row]);   collateralised: E[row] - thr(E[delayed]) (delayed < 0: no collateral yet)
+__device__ __forceinline__ DN kt_thr(const DN& e, double h)
+{
+    if (h == 0.0) return e;
+    DN r = e;
+    if (e.v > h) r.v = e.v - h;
+    else if (e.v < -h) r.v = e.v + h;
+    else r = dconst<NP>(0.0);
+    return r;
+}
+__device__ __forceinline__ DN kt_load_expo(const double* __restrict__ expo, int64_t ex_stride, int64_t off)
+{
+    DN e;
+    e.v = expo[off];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) e.d[q] = expo[(1 + q) * ex_stride + off];
+    return e;
+}
+__device__ __forceinline__ DN kt_unsecured(const double* __restrict__ expo, int64_t ex_stride, const int32_t* __restrict__ rows,
+                                           const int32_t* __restrict__ delayed, int collateralized, double h, int64_t ld, int m, int64_t i)
+{
+    const DN e = kt_load_expo(expo, ex_stride, (int64_t)ldk(rows + m) * ld + i);
+    if (!collateralized) return kt_thr(e, h);
+    if (!delayed) return e;
+    const int dm = ldk(delayed + m);
+    if (dm < 0) return e;
+    return e - kt_thr(kt_load_expo(expo, ex_stride, (int64_t)dm * ld + i), h);
+}
+
 struct KTCArgs {
     KTBook b;
     const double* __restrict__ expo;           // [1+NP][n_rows][ld] of ONE netting set (stride ex_stride between tangents)
     const int32_t* __restrict__ rows;          // [n_dates] exposure row of every metric date
+    const int32_t* __restrict__ delayed;       // [n_dates] delayed (t - MPoR) row or -1; nullptr when not collateralised
     const int32_t* __restrict__ surv;          // [n_dates-1] atom ids
     const int32_t* __restrict__ cond;
     double* __restrict__ out;                  // [1+NP][ld]
     int64_t ex_stride;
     double threshold, lgd;
-    int32_t n_dates, pad;
+    int32_t n_dates, collateralized;
 };
 
 __global__ __launch_bounds__(MCX_BLOCK) void kt_cva(const KTCArgs a)
@@ -327,17 +358,8 @@ __global__ __launch_bounds__(MCX_BLOCK) void kt_cva(const KTCArgs a)
     if (i >= a.b.n) return;
     DN cva = dconst<NP>(0.0);
     for (int m = 0; m < a.n_dates - 1; ++m) {                                             // cva_metric.py:78-96
-        const int64_t off = (int64_t)ldk(a.rows + m) * a.b.ld + i;
-        DN e;
-        e.v = a.expo[off];
-#pragma unroll
-        for (int q = 0; q < NP; ++q) e.d[q] = a.expo[(1 + q) * a.ex_stride + off];
-        // symmetric threshold (netting_set.py:48-72) then relu: gradient passes where the thresholded exposure is positive
-        const double h = a.threshold;
-        const double u = h == 0.0 ? e.v : (e.v > h ? e.v - h : (e.v < -h ? e.v + h : 0.0));
-        if (!(u > 0.0)) continue;
-        DN pos = e;
-        pos.v = u;
+        const DN pos = kt_unsecured(a.expo, a.ex_stride, a.rows, a.delayed, a.collateralized, a.threshold, a.b.ld, m, i);
+        if (!(pos.v > 0.0)) continue;                    // relu: gradient passes where the unsecured exposure is positive
         const int sa = ldk(a.surv + m), ca = ldk(a.cond + m);
         const DN sp = kt_atom(a.b, ldk_struct(&a.b.atoms[sa]), sa, i);
         const DN cs = kt_atom(a.b, ldk_struct(&a.b.atoms[ca]), ca, i);
@@ -352,27 +374,26 @@ __global__ __launch_bounds__(MCX_BLOCK) void kt_cva(const KTCArgs a)
 struct KTFArgs {
     const double* __restrict__ expo;           // [1+NP][n_rows][ld] of one netting set
     const int32_t* __restrict__ rows;
+    const int32_t* __restrict__ delayed;
     double* __restrict__ partials;             // [n_dates][gridDim.x][2*NP]
     int64_t ex_stride, n, ld;
     double threshold;
+    int32_t collateralized, pad;
 };
 
 __global__ __launch_bounds__(MCX_BLOCK) void kt_profiles(const KTFArgs a)
 {
     const int m = blockIdx.y;
-    const int64_t row_off = (int64_t)ldk(a.rows + m) * a.ld;
     double acc[2 * NP];
 #pragma unroll
     for (int q = 0; q < 2 * NP; ++q) acc[q] = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * MCX_BLOCK + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * MCX_BLOCK) {
-        const double e = a.expo[row_off + i], h = a.threshold;
-        const double u = h == 0.0 ? e : (e > h ? e - h : (e < -h ? e + h : 0.0));
-        const double wp = u > 0.0 ? 1.0 : 0.0, wn = u < 0.0 ? 1.0 : 0.0;      // torch.relu: zero gradient at 0
+        const DN u = kt_unsecured(a.expo, a.ex_stride, a.rows, a.delayed, a.collateralized, a.threshold, a.ld, m, i);
+        const double wp = u.v > 0.0 ? 1.0 : 0.0, wn = u.v < 0.0 ? 1.0 : 0.0;      // torch.relu: zero gradient at 0
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
-            const double du = a.expo[(1 + q) * a.ex_stride + row_off + i];
-            acc[q] = fma(wp, du, acc[q]);
-            acc[NP + q] = fma(wn, du, acc[NP + q]);
+            acc[q] = fma(wp, u.d[q], acc[q]);
+            acc[NP + q] = fma(wn, u.d[q], acc[NP + q]);
         }
     }
     __shared__ double lds[4];
@@ -551,7 +572,8 @@ extern "C" int mcx_tangent_eval(mcx_handle* h, const mcx_book* b, const double* 
 }
 
 extern "C" int mcx_tangent_cva(mcx_handle* h, const mcx_book* b, const double* d_datoms, const int32_t* h_rows, const int32_t* h_surv,
-                               const int32_t* h_cond, int32_t n_dates_metric, double threshold, double recovery, const double* d_expo_ns,
+                               const int32_t* h_cond, const int32_t* h_delayed, int32_t collateralized, int32_t n_dates_metric,
+                               double threshold, double recovery, const double* d_expo_ns,
                                int64_t expo_tangent_stride, const double* d_paths, const double* d_dpaths, int64_t n_paths, int64_t ld,
                                int32_t n_dates, double* d_out, void* stream)
 {
@@ -560,8 +582,9 @@ extern "C" int mcx_tangent_cva(mcx_handle* h, const mcx_book* b, const double* d
     for (int m = 0; m < n_dates_metric - 1; ++m)
         if (h_surv[m] < 0 || h_surv[m] >= b->n_atoms || h_cond[m] < 0 || h_cond[m] >= b->n_atoms) MCX_FAIL(h, -2, "mcx_tangent_cva: atom out of range");
     hipStream_t s = (hipStream_t)stream;
-    DevBuf rows, surv, cond;
+    DevBuf rows, surv, cond, delayed;
     MCX_HIP(h, rows.upload(h_rows, sizeof(int32_t) * (size_t)n_dates_metric, s));
+    if (h_delayed) MCX_HIP(h, delayed.upload(h_delayed, sizeof(int32_t) * (size_t)n_dates_metric, s));
     MCX_HIP(h, surv.upload(h_surv, sizeof(int32_t) * (size_t)(n_dates_metric - 1), s));
     MCX_HIP(h, cond.upload(h_cond, sizeof(int32_t) * (size_t)(n_dates_metric - 1), s));
     KTCArgs a;
@@ -569,13 +592,15 @@ extern "C" int mcx_tangent_cva(mcx_handle* h, const mcx_book* b, const double* d
     fill_book(h, b, d_datoms, d_paths, d_dpaths, n_paths, ld, n_dates, &a.b);
     a.expo = d_expo_ns; a.rows = (const int32_t*)rows.p; a.surv = (const int32_t*)surv.p; a.cond = (const int32_t*)cond.p; a.out = d_out;
     a.ex_stride = expo_tangent_stride; a.threshold = threshold; a.lgd = 1.0 - recovery; a.n_dates = n_dates_metric;
+    a.delayed = h_delayed ? (const int32_t*)delayed.p : nullptr; a.collateralized = collateralized;
     hipLaunchKernelGGL(kt_cva, dim3((unsigned)((n_paths + MCX_BLOCK - 1) / MCX_BLOCK)), dim3(MCX_BLOCK), 0, s, a);
     MCX_HIP(h, hipGetLastError());
     MCX_HIP(h, hipStreamSynchronize(s));
     return 0;
 }
 
-extern "C" int mcx_tangent_profiles(mcx_handle* h, const int32_t* h_rows, int32_t n_dates_metric, double threshold, const double* d_expo_ns,
+extern "C" int mcx_tangent_profiles(mcx_handle* h, const int32_t* h_rows, const int32_t* h_delayed, int32_t collateralized,
+                                    int32_t n_dates_metric, double threshold, const double* d_expo_ns,
                                     int64_t expo_tangent_stride, int64_t n_paths, int64_t ld, double* h_out, void* stream)
 {
     if (!h || !h_rows || !d_expo_ns || !h_out) return -1;
@@ -585,11 +610,13 @@ extern "C" int mcx_tangent_profiles(mcx_handle* h, const int32_t* h_rows, int32_
     hipStream_t s = (hipStream_t)stream;
     const int grid = mcx_grid_for(n_paths, MCX_BLOCK, 64);
     std::vector<double> part((size_t)n_dates_metric * grid * 2 * NP);
-    DevBuf rows, d_part;
+    DevBuf rows, d_part, delayed;
     MCX_HIP(h, rows.upload(h_rows, sizeof(int32_t) * (size_t)n_dates_metric, s));
+    if (h_delayed) MCX_HIP(h, delayed.upload(h_delayed, sizeof(int32_t) * (size_t)n_dates_metric, s));
     MCX_HIP(h, hipMalloc(&d_part.p, sizeof(double) * part.size()));
     KTFArgs a;
-    a.expo = d_expo_ns; a.rows = (const int32_t*)rows.p; a.partials = (double*)d_part.p; a.ex_stride = expo_tangent_stride;
+    a.expo = d_expo_ns; a.rows = (const int32_t*)rows.p; a.delayed = h_delayed ? (const int32_t*)delayed.p : nullptr;
+    a.collateralized = collateralized; a.pad = 0; a.partials = (double*)d_part.p; a.ex_stride = expo_tangent_stride;
     a.n = n_paths; a.ld = ld; a.threshold = threshold;
     hipLaunchKernelGGL(kt_profiles, dim3(grid, n_dates_metric), dim3(MCX_BLOCK), 0, s, a);
     MCX_HIP(h, hipGetLastError());

@@ -262,25 +262,29 @@ class HipBackend:
         return cfs, expo
 
     def tangent_cva(self, book, datoms: torch.Tensor, rows, surv, cond, threshold: float, recovery: float, expo: torch.Tensor,
-                    ns_i: int, paths: torch.Tensor, dpaths: torch.Tensor) -> torch.Tensor:
+                    ns_i: int, paths: torch.Tensor, dpaths: torch.Tensor, delayed=None, collateralized=False) -> torch.Tensor:
         n = paths.shape[2]
+        dl = None if delayed is None else np.ascontiguousarray(delayed, dtype=np.int32)
         r, s, c = (np.ascontiguousarray(x, dtype=np.int32) for x in (rows, surv, cond))
         out = self.empty(1 + _abi.TANGENT_NP, n)
         stride = expo.shape[1] * expo.shape[2] * expo.shape[3]
         self._check(self.lib.mcx_tangent_cva(
-            self.h, book.ptr, _vp(datoms.data_ptr()), _abi.ptr(r), _abi.ptr(s), _abi.ptr(c), C.c_int32(len(r)),
+            self.h, book.ptr, _vp(datoms.data_ptr()), _abi.ptr(r), _abi.ptr(s), _abi.ptr(c),
+            _abi.ptr(dl) if dl is not None else None, C.c_int32(int(collateralized)), C.c_int32(len(r)),
             C.c_double(threshold), C.c_double(recovery), _vp(expo[0, ns_i].data_ptr()), C.c_int64(stride), _vp(paths.data_ptr()),
             _vp(dpaths.data_ptr()), C.c_int64(n), C.c_int64(n), C.c_int32(paths.shape[0]), _vp(out.data_ptr()), self._stream()),
             "mcx_tangent_cva")
         return out
 
-    def tangent_profiles(self, rows, threshold: float, expo: torch.Tensor, ns_i: int) -> np.ndarray:
+    def tangent_profiles(self, rows, threshold: float, expo: torch.Tensor, ns_i: int, delayed=None, collateralized=False) -> np.ndarray:
         """-> [n_dates][2][NP] local sums of 1[u>0] du (EPE) and 1[u<0] du (ENE)"""
         r = np.ascontiguousarray(rows, dtype=np.int32)
+        dl = None if delayed is None else np.ascontiguousarray(delayed, dtype=np.int32)
         out = np.zeros((len(r), 2, _abi.TANGENT_NP))
         n = expo.shape[3]
         stride = expo.shape[1] * expo.shape[2] * expo.shape[3]
-        self._check(self.lib.mcx_tangent_profiles(self.h, _abi.ptr(r), C.c_int32(len(r)), C.c_double(threshold),
+        self._check(self.lib.mcx_tangent_profiles(self.h, _abi.ptr(r), _abi.ptr(dl) if dl is not None else None,
+                                                  C.c_int32(int(collateralized)), C.c_int32(len(r)), C.c_double(threshold),
                                                   _vp(expo[0, ns_i].data_ptr()), C.c_int64(stride), C.c_int64(n), C.c_int64(n),
                                                   _abi.ptr(out), self._stream()), "mcx_tangent_profiles")
         return out

@@ -254,8 +254,8 @@ def run_with_tangent_book(sc):
     if sc.requires_higher_order_derivatives:
         raise _NoTangentForm("second order")
     rm = sc.risk_metrics
-    if sc.simulation_scheme.name != "EULER" or any(ns.is_collateralized() for ns in sc.netting_sets):
-        raise _NoTangentForm("scheme / collateral")
+    if sc.simulation_scheme.name != "EULER":
+        raise _NoTangentForm("scheme")
     if any(m.metric_type not in (MetricType.PV, MetricType.CVA, MetricType.EPE, MetricType.ENE, MetricType.CE, MetricType.EEPE)
            or not m._native for m in rm.metrics):
         raise _NoTangentForm("metric")
@@ -354,13 +354,15 @@ def run_with_tangent_book(sc):
         cfs, expo = be.tangent_eval(book, datoms, be.from_numpy(coeffs), be.from_numpy(dcoeffs), paths, dpaths)
         for ns_i, ns in enumerate(sc.netting_sets):
             prof = None
+            coll = ns.is_collateralized()
+            delayed = base.netting_set_delayed_exposure_indices[ns_i].numpy().astype(np.int32) if coll else None
             for m_i, m in enumerate(rm.metrics):
                 if m.metric_type == MetricType.PV:
                     for q, j in enumerate(sel):
                         grads[ns_i][m_i][0][j] = mean_of(cfs[1 + q, ns_i])
                 elif m.metric_type in (MetricType.EPE, MetricType.ENE, MetricType.CE, MetricType.EEPE):
                     if prof is None:            # [dates][2][NP] sums of 1[u>0] du / 1[u<0] du over all ranks
-                        prof = shard.all_reduce_np(be.tangent_profiles(rows, ns.threshold, expo, ns_i)) / float(sc.num_paths_mainsim)
+                        prof = shard.all_reduce_np(be.tangent_profiles(rows, ns.threshold, expo, ns_i, delayed, coll)) / float(sc.num_paths_mainsim)
                     for q, j in enumerate(sel):
                         if m.metric_type == MetricType.CE:           # positive part of the first exposure date (ce_metric.py)
                             grads[ns_i][m_i][0][j] = float(prof[0, 0, q])
@@ -372,7 +374,7 @@ def run_with_tangent_book(sc):
                                 grads[ns_i][m_i][e_i][j] = float(prof[e_i, side, q])
                 elif not (ns.counterparty_id is not None and m.counterparty_id != ns.counterparty_id):
                     surv, cond = base._cva_atoms[m_i]
-                    out = be.tangent_cva(book, datoms, rows, surv, cond, ns.threshold, m.recovery_rate, expo, ns_i, paths, dpaths)
+                    out = be.tangent_cva(book, datoms, rows, surv, cond, ns.threshold, m.recovery_rate, expo, ns_i, paths, dpaths, delayed, coll)
                     for q, j in enumerate(sel):
                         grads[ns_i][m_i][0][j] = mean_of(out[1 + q])
         del paths, dpaths, cfs, expo

@@ -341,3 +341,25 @@ def test_rccl_collectives_single_rank_group(hip):
     sc2, _ = cases.make_controller("irs_cva", hip, inject=False)
     b = sc2.run_simulation().results[0][0][0]
     assert a[0] == b[0]
+
+
+def test_forward_mode_collateralised_netting_set_matches_bumps(hip):
+    """margin-period-of-risk collateral and a threshold in the dual CVA / profile kernels (netting_set.py:110-184): forward mode
+    vs common-random-number bumps, same Philox stream"""
+    from mcx.products.swap import InterestRateSwap, IRSType
+    out = {}
+    for fwd in (True, False):
+        _, model, _ = cases.irs_cva()
+        irs = InterestRateSwap(0.0, 2.5, 1.0, 0.03, 0.25, 0.25, IRSType.PAYER, "irs")
+        ns = [cases.NettingSet(name="coll", products=[irs], counterparty_id="cp", threshold=0.002, margin_period_of_risk=0.25)]
+        rm = cases.RiskMetrics([cases.CVAMetric("cp", 0.4), cases.EPEMetric()], exposure_timeline=np.arange(11) * 0.25)
+        sc = cases.SimulationController(ns, model, rm, 8192, 4096, 3, cases.E, differentiate=True, backend=hip)
+        sc.forward_mode = fwd
+        r = sc.run_simulation()
+        assert bool(sc.timings.get("tangent")) == fwd, sc.timings
+        out[fwd] = (np.array(r.derivatives[0][0][0]), np.array(r.derivatives[0][1]), np.array(r.results[0][0]))
+    assert np.allclose(out[True][2], out[False][2], rtol=1e-12)
+    for k in (0, 1):
+        scale = np.abs(out[False][k]).max()
+        # (a bumped path crossing the threshold / relu kink shows up as ~1e-5 in ONE entry of the finite difference)
+        assert scale > 0 and np.allclose(out[True][k], out[False][k], rtol=5e-5, atol=3e-5 * scale), (k, out[True][k], out[False][k])
