@@ -1,4 +1,5 @@
-"""Collection of metrics + the pathwise primitives they need (reference: metrics/risk_metrics.py:9-69)."""
+"""The set of metrics of a run and what they need from the simulation: discounted cashflows (PV) and / or exposure profiles
+(everything else).  Same constructor and query methods as the reference's metrics/risk_metrics.py."""
 from __future__ import annotations
 
 from enum import Enum
@@ -17,38 +18,31 @@ class PathwisePrimitive(Enum):
 
 class RiskMetrics:
     def __init__(self, metrics: list[Metric], exposure_timeline=None):
+        dates = np.asarray([] if exposure_timeline is None else exposure_timeline, dtype=np.float64).reshape(-1)
+        kinds = {m.metric_type for m in metrics}
         self.metrics = metrics
-        if exposure_timeline is None:
-            exposure_timeline = []
-        self.exposure_timeline = torch.tensor(np.asarray(exposure_timeline, dtype=np.float64), dtype=FLOAT, device=device)
-        self.any_pv = any(m.metric_type == MetricType.PV for m in metrics)
-        self.any_xva = any(m.metric_type == MetricType.CVA for m in metrics)
-        self.any_exposure = any(m.metric_type != MetricType.PV for m in metrics)
-        prims = []
-        if self.any_pv:
-            prims.append(PathwisePrimitive.DISCOUNTED_CASHFLOWS)
-        if self.any_exposure:
-            prims.append(PathwisePrimitive.EXPOSURE_PROFILES)
-        self._required_primitives = frozenset(prims)
-        if self.any_exposure:
-            assert len(exposure_timeline) > 0, \
-                "For exposure simulation at least one exposure time point needs to be provided."
-        for m in self.metrics:
-            m.set_requests(exposure_timeline)
+        self.any_pv = MetricType.PV in kinds
+        self.any_xva = MetricType.CVA in kinds
+        self.any_exposure = bool(kinds - {MetricType.PV})
+        if self.any_exposure and dates.size == 0:
+            raise AssertionError("For exposure simulation at least one exposure time point needs to be provided.")
+        self.exposure_timeline = torch.tensor(dates, dtype=FLOAT, device=device)
+        self._required_primitives = frozenset(
+            prim for prim, wanted in ((PathwisePrimitive.DISCOUNTED_CASHFLOWS, self.any_pv),
+                                      (PathwisePrimitive.EXPOSURE_PROFILES, self.any_exposure)) if wanted)
         self.counterparty_ids: list[str] = []
-        for m in self.metrics:
-            ids = m.get_counterparty_ids()
-            if ids is not None:
-                self.counterparty_ids.extend(ids)
-
-    def requires_discounted_cashflows(self) -> bool:
-        return self.requires_primitive(PathwisePrimitive.DISCOUNTED_CASHFLOWS)
-
-    def requires_exposure_profiles(self) -> bool:
-        return self.requires_primitive(PathwisePrimitive.EXPOSURE_PROFILES)
+        for metric in metrics:
+            metric.set_requests([] if exposure_timeline is None else exposure_timeline)
+            self.counterparty_ids += list(metric.get_counterparty_ids() or [])
 
     def required_pathwise_primitives(self):
         return self._required_primitives
 
     def requires_primitive(self, primitive: PathwisePrimitive) -> bool:
         return primitive in self._required_primitives
+
+    def requires_discounted_cashflows(self) -> bool:
+        return PathwisePrimitive.DISCOUNTED_CASHFLOWS in self._required_primitives
+
+    def requires_exposure_profiles(self) -> bool:
+        return PathwisePrimitive.EXPOSURE_PROFILES in self._required_primitives
