@@ -503,6 +503,14 @@ extern "C" int mcx_tangent_lsm(mcx_handle* h, const mcx_book* b, int32_t product
     if (pr.n_states != 1) MCX_FAIL(h, MCX_E_NOT_FUSABLE, "mcx_tangent_lsm: stateless products only");
     const int n_cf = pr.cf_end - pr.cf_begin;
     if (first_event < 0 || first_event > n_cf) MCX_FAIL(h, -2, "mcx_tangent_lsm: first_event out of range");
+    for (int q = pr.cf_begin; q < pr.cf_end; ++q) {
+        const DevEvent& e = b->h_events[q];
+        if (!(e.kind == MCX_EV_CASHFLOW || (e.kind == MCX_EV_OPTION && e.aux[0] == 0.0)))
+            MCX_FAIL(h, MCX_E_NOT_FUSABLE, "mcx_tangent_lsm: event %d (kind %d, mode %g) has no tangent form", q, e.kind, e.aux[0]);
+        if (e.kind == MCX_EV_OPTION)
+            for (int j = e.term_begin; j < e.term_end; ++j)
+                if (b->h_terms[j].den >= 0) MCX_FAIL(h, MCX_E_NOT_FUSABLE, "mcx_tangent_lsm: option over per-term denominators");
+    }
     if (num_atom < 0 || num_atom >= b->n_atoms || x_atom < 0 || x_atom >= b->n_atoms) MCX_FAIL(h, -2, "mcx_tangent_lsm: atom out of range");
     const int K = b->n_basis, NM = (2 * K - 1) + K;
     if (n_paths <= 0) { memset(h_moments, 0, sizeof(double) * (size_t)(1 + NP) * NM); return 0; }

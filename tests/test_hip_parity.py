@@ -363,3 +363,16 @@ def test_forward_mode_collateralised_netting_set_matches_bumps(hip):
         scale = np.abs(out[False][k]).max()
         # (a bumped path crossing the threshold / relu kink shows up as ~1e-5 in ONE entry of the finite difference)
         assert scale > 0 and np.allclose(out[True][k], out[False][k], rtol=5e-5, atol=3e-5 * scale), (k, out[True][k], out[False][k])
+
+
+def test_forward_mode_falls_back_to_bumps_for_events_without_tangent_form(hip):
+    """a binary payoff has no dual form in kt_book.hip: the library answers MCX_E_NOT_FUSABLE and differentiate=True completes
+    with common-random-number bumps"""
+    model = cases.BlackScholesModel(0.0, 100.0, 0.03, 0.2, asset_id="asset")
+    prod = cases.BinaryOption(1.0, 100.0, 10.0, cases.OptionType.CALL, asset_id="asset")
+    sc = cases.SimulationController([cases.NettingSet(name="bin", products=[prod])], model, cases.RiskMetrics([cases.PVMetric()]),
+                                    4096, 0, 4, cases.E, differentiate=True, backend=hip)
+    res = sc.run_simulation()
+    assert sc.timings.get("tangent") is False and sc.timings.get("bumped_passes") == 6
+    d = res.get_derivatives("bin", "pv", evaluation_idx=0)
+    assert all(np.isfinite(float(v)) for v in d.values()) and float(d["spot"]) > 0.0
