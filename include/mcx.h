@@ -327,7 +327,9 @@ int  mcx_tangent_lsm(mcx_handle* h, const mcx_book* book, int32_t product, int32
                      int64_t n_paths, int64_t ld, int32_t n_dates, double* h_moments, void* stream);
 int  mcx_tangent_eval(mcx_handle* h, const mcx_book* book, const double* d_datoms, const double* d_coeffs, const double* d_dcoeffs,
                       const double* d_paths, const double* d_dpaths, int64_t n_paths, int64_t ld, int32_t n_dates,
-                      double* d_cfs, double* d_expo, void* stream);
+                      double* d_cfs, double* d_expo,
+                      const int32_t* h_ev_param /* nullable [n_events][2]: tangent slot (or -1) of sigma / rate of EXPO_BS events */,
+                      void* stream);
 /* per-path CVA of one netting set with tangents: d_out [1+NP][ld]; d_expo_ns = the netting set's block of d_expo,
  * expo_tangent_stride = doubles between consecutive tangent images (n_ns * n_rows * ld) */
 /* EPE / ENE profile tangents of one netting set: h_out [n_dates_metric][2][NP] = sum over the local paths of 1[u > 0] du and of

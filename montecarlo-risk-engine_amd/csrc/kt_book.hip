@@ -268,6 +268,7 @@ struct KTEArgs {
     const double* __restrict__ dcoeffs;        // [n_coeffs][NP]
     double* __restrict__ cfs;                  // [1+NP][n_ns][ld]   (zero-initialised)
     double* __restrict__ expo;                 // [1+NP][n_ns][n_rows][ld] (zero-initialised)
+    const int32_t* __restrict__ ev_param;      // [n_events][2] tangent slot (0..NP-1 or -1) of an EXPO_BS event's sigma / rate; nullable
     int32_t n_products, n_ns, n_rows, pad;
 };
 
@@ -285,9 +286,34 @@ __global__ __launch_bounds__(MCX_BLOCK) void kt_eval(const KTEArgs a)
             const KTEventIds id = ldk_struct(&a.ev_ids[q]);
             if (e.kind <= MCX_EV_OPTION) {
                 acc = acc + kt_cash_event(a.b, e, id, a.term_atom, i);
-            } else {                                                                      // MCX_EV_EXPO_POLY (controller.py:439-447)
+            } else {                                                                      // exposures (controller.py:430-447)
                 DN v = dconst<NP>(0.0);
-                if (e.coeff_off >= 0) {
+                if (e.kind == MCX_EV_EXPO_BS) {
+                    // analytic Black-Scholes exposure (european_option.py:123-145) in dual numbers: sigma and rate are model
+                    // parameters (their tangent slots come from the host), the spot is the path state
+                    if (e.aux[2] > 0.0) {
+                        DN sig = dconst<NP>(e.aux[0]), rate = dconst<NP>(e.aux[1]);
+                        const int s_sig = a.ev_param ? ldk(a.ev_param + 2 * q) : -1, s_rate = a.ev_param ? ldk(a.ev_param + 2 * q + 1) : -1;
+#pragma unroll
+                        for (int r = 0; r < NP; ++r) { sig.d[r] = (r == s_sig) ? 1.0 : 0.0; rate.d[r] = (r == s_rate) ? 1.0 : 0.0; }
+                        const double tau = e.aux[2], sq = sqrt(tau);
+                        const DN spot = kt_atom(a.b, e.x, id.x, i);
+                        const DN d1 = (dlog(spot * (1.0 / e.strike)) + (rate + sig * sig * 0.5) * tau) / (sig * sq);
+                        const DN d2 = d1 - sig * sq;
+                        const DN df = dexp(rate * (-tau));
+                        auto ncdf = [](const DN& x) {                      // Phi(x), d Phi = phi(x) dx
+                            DN r;
+                            r.v = 0.5 * (1.0 + erf(x.v * 0.70710678118654752440));
+                            const double pdf = 0.39894228040143267794 * exp(-0.5 * x.v * x.v);
+#pragma unroll
+                            for (int q2 = 0; q2 < NP; ++q2) r.d[q2] = pdf * x.d[q2];
+                            return r;
+                        };
+                        const DN price = e.sign > 0.0 ? spot * ncdf(d1) - df * ncdf(d2) * e.strike
+                                                      : df * ncdf(d2 * -1.0) * e.strike - spot * ncdf(d1 * -1.0);
+                        v = price / kt_atom(a.b, e.num, id.num, i);
+                    }
+                } else if (e.coeff_off >= 0) {
                     const DN x = kt_atom(a.b, e.x, id.x, i);
                     DN xp = dconst<NP>(1.0);
                     for (int k = 0; k < K; ++k) {
@@ -546,7 +572,7 @@ extern "C" int mcx_tangent_lsm(mcx_handle* h, const mcx_book* b, int32_t product
 
 extern "C" int mcx_tangent_eval(mcx_handle* h, const mcx_book* b, const double* d_datoms, const double* d_coeffs, const double* d_dcoeffs,
                                 const double* d_paths, const double* d_dpaths, int64_t n_paths, int64_t ld, int32_t n_dates,
-                                double* d_cfs, double* d_expo, void* stream)
+                                double* d_cfs, double* d_expo, const int32_t* h_ev_param, void* stream)
 {
     if (!h || !b || !d_datoms || !d_coeffs || !d_dcoeffs || !d_paths || !d_dpaths || !d_cfs || !d_expo) return -1;
     if (n_paths <= 0) return 0;
@@ -555,7 +581,8 @@ extern "C" int mcx_tangent_eval(mcx_handle* h, const mcx_book* b, const double* 
         if (pr.n_states != 1) MCX_FAIL(h, MCX_E_NOT_FUSABLE, "mcx_tangent_eval: product %d has exercise states", p);
         for (int q = pr.ev_begin; q < pr.ev_end; ++q) {
             const DevEvent& e = b->h_events[q];
-            const bool ok = e.kind == MCX_EV_CASHFLOW || (e.kind == MCX_EV_OPTION && e.aux[0] == 0.0) || e.kind == MCX_EV_EXPO_POLY;
+            const bool ok = e.kind == MCX_EV_CASHFLOW || (e.kind == MCX_EV_OPTION && e.aux[0] == 0.0) || e.kind == MCX_EV_EXPO_POLY ||
+                            (e.kind == MCX_EV_EXPO_BS && h_ev_param != nullptr);
             if (!ok) MCX_FAIL(h, MCX_E_NOT_FUSABLE, "mcx_tangent_eval: event %d (kind %d) has no tangent form", q, e.kind);
             if (e.kind == MCX_EV_OPTION)
                 for (int j = e.term_begin; j < e.term_end; ++j)
@@ -563,8 +590,9 @@ extern "C" int mcx_tangent_eval(mcx_handle* h, const mcx_book* b, const double* 
         }
     }
     hipStream_t s = (hipStream_t)stream;
-    DevBuf ev_ids, term_atom;
+    DevBuf ev_ids, term_atom, ev_param;
     if (int rc = upload_ids(h, b, ev_ids, term_atom, s)) return rc;
+    if (h_ev_param) MCX_HIP(h, ev_param.upload(h_ev_param, sizeof(int32_t) * 2 * (size_t)b->n_events, s));
     const int n_rows = b->n_expo_rows > 0 ? b->n_expo_rows : 1;
     MCX_HIP(h, hipMemsetAsync(d_cfs, 0, sizeof(double) * (size_t)(1 + NP) * b->n_netting_sets * ld, s));
     MCX_HIP(h, hipMemsetAsync(d_expo, 0, sizeof(double) * (size_t)(1 + NP) * b->n_netting_sets * n_rows * ld, s));
@@ -573,7 +601,7 @@ extern "C" int mcx_tangent_eval(mcx_handle* h, const mcx_book* b, const double* 
     fill_book(h, b, d_datoms, d_paths, d_dpaths, n_paths, ld, n_dates, &a.b);
     a.ev_ids = (const KTEventIds*)ev_ids.p; a.term_atom = (const int32_t*)term_atom.p; a.products = b->d_products;
     a.coeffs = d_coeffs; a.dcoeffs = d_dcoeffs; a.cfs = d_cfs; a.expo = d_expo; a.n_products = b->n_products;
-    a.n_ns = b->n_netting_sets; a.n_rows = n_rows;
+    a.n_ns = b->n_netting_sets; a.n_rows = n_rows; a.ev_param = h_ev_param ? (const int32_t*)ev_param.p : nullptr;
     hipLaunchKernelGGL(kt_eval, dim3((unsigned)((n_paths + MCX_BLOCK - 1) / MCX_BLOCK)), dim3(MCX_BLOCK), 0, s, a);
     MCX_HIP(h, hipGetLastError());
     MCX_HIP(h, hipStreamSynchronize(s));

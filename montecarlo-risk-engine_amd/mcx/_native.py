@@ -249,7 +249,7 @@ class HipBackend:
         return out
 
     def tangent_eval(self, book, datoms: torch.Tensor, coeffs: torch.Tensor, dcoeffs: torch.Tensor, paths: torch.Tensor,
-                     dpaths: torch.Tensor):
+                     dpaths: torch.Tensor, ev_param: np.ndarray | None = None):
         plan = book.plan
         n = paths.shape[2]
         NP = _abi.TANGENT_NP
@@ -258,7 +258,8 @@ class HipBackend:
         self._check(self.lib.mcx_tangent_eval(
             self.h, book.ptr, _vp(datoms.data_ptr()), _vp(coeffs.data_ptr()), _vp(dcoeffs.data_ptr()), _vp(paths.data_ptr()),
             _vp(dpaths.data_ptr()), C.c_int64(n), C.c_int64(n), C.c_int32(paths.shape[0]), _vp(cfs.data_ptr()),
-            _vp(expo.data_ptr()), self._stream()), "mcx_tangent_eval")
+            _vp(expo.data_ptr()), _abi.ptr(np.ascontiguousarray(ev_param, dtype=np.int32)) if ev_param is not None else None,
+            self._stream()), "mcx_tangent_eval")
         return cfs, expo
 
     def tangent_cva(self, book, datoms: torch.Tensor, rows, surv, cond, threshold: float, recovery: float, expo: torch.Tensor,

@@ -261,8 +261,7 @@ def run_with_tangent_book(sc):
         raise _NoTangentForm("metric")
     if any(p.get_num_states() != 1 for p in sc.products) or len(sc.products) > 64:
         raise _NoTangentForm("products")
-    if any(sc._can_skip_monte_carlo_for_product(p) or
-           (rm.requires_exposure_profiles() and sc._can_use_analytic_exposure_for_product(p)) for p in sc.products):
+    if any(sc._can_skip_monte_carlo_for_product(p) for p in sc.products):
         raise _NoTangentForm("analytic shortcuts")
     t0 = time.perf_counter()
     be, shard = sc.backend, Shard()
@@ -351,7 +350,19 @@ def run_with_tangent_book(sc):
         off, n_main = shard.split(sc.num_paths_mainsim)
         paths, dpaths = be.tangent_paths(sim, dslot, dinit, daux, 43 + sc.seed_offset, off, n_main,
                                          sc._inject.get("main", (None, None))[0])
-        cfs, expo = be.tangent_eval(book, datoms, be.from_numpy(coeffs), be.from_numpy(dcoeffs), paths, dpaths)
+        # analytic Black-Scholes exposure events: which tangent slot of this pass is their sigma / their rate
+        ev_param = None
+        ev_kind = base.book_plan.events["kind"]
+        if (ev_kind == _abi.EV_EXPO_BS).any():
+            ev_param = np.full((len(ev_kind), 2), -1, dtype=np.int32)
+            for p_i, p in enumerate(sc.products):
+                if hasattr(p, "_bs_param_indices") and base._can_use_analytic_exposure_for_product(p):
+                    _i_s, i_v, i_r = p._bs_param_indices(sc.model)
+                    b0, b1 = int(base.book_plan.products["ev_begin"][p_i]), int(base.book_plan.products["ev_end"][p_i])
+                    rows_bs = np.arange(b0, b1)[ev_kind[b0:b1] == _abi.EV_EXPO_BS]
+                    ev_param[rows_bs, 0] = sel.index(i_v) if i_v in sel else -1
+                    ev_param[rows_bs, 1] = sel.index(i_r) if i_r in sel else -1
+        cfs, expo = be.tangent_eval(book, datoms, be.from_numpy(coeffs), be.from_numpy(dcoeffs), paths, dpaths, ev_param)
         for ns_i, ns in enumerate(sc.netting_sets):
             prof = None
             coll = ns.is_collateralized()

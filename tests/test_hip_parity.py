@@ -376,3 +376,24 @@ def test_forward_mode_falls_back_to_bumps_for_events_without_tangent_form(hip):
     assert sc.timings.get("tangent") is False and sc.timings.get("bumped_passes") == 6
     d = res.get_derivatives("bin", "pv", evaluation_idx=0)
     assert all(np.isfinite(float(v)) for v in d.values()) and float(d["spot"]) > 0.0
+
+
+def test_forward_mode_analytic_black_scholes_exposures_match_bumps(hip):
+    """EPE / PV sensitivities of a European option book whose exposures are the Black-Scholes closed form
+    (european_option.py:123-145, MCX_EV_EXPO_BS): dual-number evaluation vs common-random-number bumps"""
+    out = {}
+    for fwd in (True, False):
+        model = cases.BlackScholesModel(0.0, 100.0, 0.03, 0.25)
+        c = cases.EuropeanOption(cases.Equity(), 1.0, 95.0, cases.OptionType.CALL); c.name = "call"
+        p = cases.EuropeanOption(cases.Equity(), 1.5, 110.0, cases.OptionType.PUT); p.name = "put"
+        ns = [cases.NettingSet(name="opts", products=[c, p])]
+        rm = cases.RiskMetrics([cases.EPEMetric(), cases.PVMetric()], exposure_timeline=np.array([0.0, 0.25, 0.5, 1.0, 1.25, 1.5, 2.0]))
+        sc = cases.SimulationController(ns, model, rm, 16384, 0, 4, cases.E, differentiate=True, backend=hip)
+        sc.forward_mode = fwd
+        r = sc.run_simulation()
+        assert bool(sc.timings.get("tangent")) == fwd, sc.timings
+        out[fwd] = (np.array(r.derivatives[0][0]), np.array(r.derivatives[0][1]), np.array(r.results[0][0]))
+    assert np.allclose(out[True][2], out[False][2], rtol=1e-12)
+    for k in (0, 1):
+        scale = np.abs(out[False][k]).max()
+        assert scale > 0 and np.allclose(out[True][k], out[False][k], rtol=1e-4, atol=3e-5 * scale), (k, out[True][k], out[False][k])
