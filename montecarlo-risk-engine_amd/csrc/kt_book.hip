@@ -12,8 +12,7 @@
 // closed-form coefficients of each atom) arrive as arrays next to the primal descriptors (mcx/aad.py builds them).
 // Scope: EULER scheme; Black-Scholes / Vasicek / CIR++ (stochastic and deterministic) slots; stateless products (cashflow and
 // plain option events, polynomial and analytic Black-Scholes exposures); thresholds and MPoR collateral in the metric kernels.
-// Anything else keeps the
-// common-random-number bump path.
+// Anything else keeps the common-random-number bump path.
 #include "mcx_dual.h"
 
 namespace {
