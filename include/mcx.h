@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MCX_ABI_VERSION 1
+#define MCX_ABI_VERSION 2   /* 2: batched LSM, tangent-book kernels, bridge RNG, option aggregation modes, 8 exercise states */
 
 #define MCX_MAX_SLOTS   8    /* sub-models in one ModelConfig                                  */
 #define MCX_MAX_Z       8    /* total simulation dimension (correlated normals per sub-step)    */
