@@ -116,6 +116,22 @@ __device__ __forceinline__ void k3_roll(const K3Args& a, int64_t i, double (&y)[
     for (int s = 0; s < S; ++s) y[s] = num * w[s];
 }
 
+// block reduction of NM per-lane accumulators with a single barrier: wave64 shuffles, one LDS row per wave, thread q sums the
+// four rows (the per-accumulator block_sum paid two barriers for each of the NM values)
+template <int NM>
+__device__ __forceinline__ void k3_block_reduce(const double (&acc)[NM], double* __restrict__ dst)
+{
+    __shared__ double rows[4][NM];
+    const int lane = threadIdx.x & (MCX_WAVE - 1), wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NM; ++q) {
+        const double r = wave_sum(acc[q]);
+        if (lane == 0) rows[wv][q] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x < NM) dst[threadIdx.x] = (rows[0][threadIdx.x] + rows[1][threadIdx.x]) + (rows[2][threadIdx.x] + rows[3][threadIdx.x]);
+}
+
 template <int K, int S>
 __global__ __launch_bounds__(MCX_BLOCK) void k3_step_valu(const K3Args a)
 {
@@ -137,12 +153,7 @@ __global__ __launch_bounds__(MCX_BLOCK) void k3_step_valu(const K3Args a)
             zp *= z;
         }
     }
-    __shared__ double lds[4];
-#pragma unroll
-    for (int q = 0; q < NM; ++q) {
-        const double r = block_sum(acc[q], lds);
-        if (threadIdx.x == 0) a.partials[(int64_t)blockIdx.x * NM + q] = r;
-    }
+    k3_block_reduce<NM>(acc, a.partials + (int64_t)blockIdx.x * NM);
 }
 
 // ---- MFMA variant ----------------------------------------------------------------------------------------------------
@@ -237,12 +248,7 @@ __global__ __launch_bounds__(MCX_BLOCK) void k3_step_batch(K3Args a, const K3Job
             zp *= z;
         }
     }
-    __shared__ double lds[4];
-#pragma unroll
-    for (int q = 0; q < NM; ++q) {
-        const double r = block_sum(acc[q], lds);
-        if (threadIdx.x == 0) a.partials[((int64_t)blockIdx.y * blocks_per_job + blockIdx.x) * NM + q] = r;
-    }
+    k3_block_reduce<NM>(acc, a.partials + ((int64_t)blockIdx.y * blocks_per_job + blockIdx.x) * NM);
 }
 
 // out[job][q] = sum over the job's blocks (fixed order: deterministic)
