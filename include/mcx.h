@@ -337,6 +337,12 @@ int  mcx_tangent_eval(mcx_handle* h, const mcx_book* book, const double* d_datom
 int  mcx_tangent_profiles(mcx_handle* h, const int32_t* h_rows, const int32_t* h_delayed /* nullable */, int32_t collateralized,
                           int32_t n_dates_metric, double threshold, const double* d_expo_ns,
                           int64_t expo_tangent_stride, int64_t n_paths, int64_t ld, double* h_out, void* stream);
+/* PFE tangent: for every metric date the local path with the smallest index whose unsecured exposure equals h_targets[m] (the
+ * exact order statistic from the radix select): h_out [n_dates_metric][1+NP] = (index or -1, its tangent) — the reference
+ * differentiates through torch.sort, i.e. through the selected element (pfe_metric.py:61-66) */
+int  mcx_tangent_pick(mcx_handle* h, const int32_t* h_rows, const int32_t* h_delayed /* nullable */, int32_t collateralized,
+                      int32_t n_dates_metric, double threshold, const double* h_targets, const double* d_expo_ns,
+                      int64_t expo_tangent_stride, int64_t n_paths, int64_t ld, double* h_out, void* stream);
 int  mcx_tangent_cva(mcx_handle* h, const mcx_book* book, const double* d_datoms, const int32_t* h_rows, const int32_t* h_surv,
                      const int32_t* h_cond, const int32_t* h_delayed /* nullable: rows at t - MPoR */, int32_t collateralized,
                      int32_t n_dates_metric, double threshold, double recovery, const double* d_expo_ns,

@@ -431,6 +431,48 @@ __global__ __launch_bounds__(MCX_BLOCK) void kt_profiles(const KTFArgs a)
     }
 }
 
+// ---- PFE tangent: d x_(r) / d theta = the tangent of the path that realises the order statistic (pfe_metric.py:61-66: the
+// reference differentiates through torch.sort, i.e. through the selected element) -------------------------------------------
+struct KTQArgs {
+    const double* __restrict__ expo;
+    const int32_t* __restrict__ rows;
+    const int32_t* __restrict__ delayed;
+    const double* __restrict__ targets;        // [n_dates] exact order statistic of the unsecured exposure (K5 radix select)
+    unsigned long long* __restrict__ first;    // [n_dates] smallest local path index with u == target (init: ~0)
+    double* __restrict__ out;                  // [n_dates][1+NP]: index (or -1), tangent
+    int64_t ex_stride, n, ld;
+    double threshold;
+    int32_t collateralized, pad;
+};
+
+__global__ __launch_bounds__(MCX_BLOCK) void kt_pick_find(const KTQArgs a)
+{
+    const int m = blockIdx.y;
+    const double target = ldk(a.targets + m);
+    unsigned long long best = ~0ull;
+    for (int64_t i = (int64_t)blockIdx.x * MCX_BLOCK + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * MCX_BLOCK) {
+        const DN u = kt_unsecured(a.expo, a.ex_stride, a.rows, a.delayed, a.collateralized, a.threshold, a.ld, m, i);
+        if (u.v == target && (unsigned long long)i < best) best = (unsigned long long)i;
+    }
+    if (best != ~0ull) atomicMin(a.first + m, best);
+}
+
+__global__ void kt_pick_read(const KTQArgs a, int n_dates)
+{
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n_dates) return;
+    const unsigned long long i = a.first[m];
+    double* o = a.out + (int64_t)m * (1 + NP);
+    if (i == ~0ull) {
+        o[0] = -1.0;
+        for (int q = 0; q < NP; ++q) o[1 + q] = 0.0;
+        return;
+    }
+    const DN u = kt_unsecured(a.expo, a.ex_stride, a.rows, a.delayed, a.collateralized, a.threshold, a.ld, m, (int64_t)i);
+    o[0] = (double)i;
+    for (int q = 0; q < NP; ++q) o[1 + q] = u.d[q];
+}
+
 template <int NSLOT, int NZ>
 void launch_ktp(const KTPArgs& a, int grid, bool inject, hipStream_t s)
 {
@@ -662,5 +704,33 @@ extern "C" int mcx_tangent_profiles(mcx_handle* h, const int32_t* h_rows, const 
     for (int m = 0; m < n_dates_metric; ++m)
         for (int b = 0; b < grid; ++b)
             for (int q = 0; q < 2 * NP; ++q) h_out[(size_t)m * 2 * NP + q] += part[((size_t)m * grid + b) * 2 * NP + q];
+    return 0;
+}
+
+extern "C" int mcx_tangent_pick(mcx_handle* h, const int32_t* h_rows, const int32_t* h_delayed, int32_t collateralized,
+                                int32_t n_dates_metric, double threshold, const double* h_targets, const double* d_expo_ns,
+                                int64_t expo_tangent_stride, int64_t n_paths, int64_t ld, double* h_out, void* stream)
+{
+    if (!h || !h_rows || !h_targets || !d_expo_ns || !h_out) return -1;
+    if (n_dates_metric <= 0) return 0;
+    for (int m = 0; m < n_dates_metric; ++m) { h_out[(size_t)m * (1 + NP)] = -1.0; for (int q = 0; q < NP; ++q) h_out[(size_t)m * (1 + NP) + 1 + q] = 0.0; }
+    if (n_paths <= 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    DevBuf rows, delayed, targets, first, out;
+    MCX_HIP(h, rows.upload(h_rows, sizeof(int32_t) * (size_t)n_dates_metric, s));
+    if (h_delayed) MCX_HIP(h, delayed.upload(h_delayed, sizeof(int32_t) * (size_t)n_dates_metric, s));
+    MCX_HIP(h, targets.upload(h_targets, sizeof(double) * (size_t)n_dates_metric, s));
+    MCX_HIP(h, hipMalloc(&first.p, sizeof(unsigned long long) * (size_t)n_dates_metric));
+    MCX_HIP(h, hipMemsetAsync(first.p, 0xFF, sizeof(unsigned long long) * (size_t)n_dates_metric, s));
+    MCX_HIP(h, hipMalloc(&out.p, sizeof(double) * (size_t)n_dates_metric * (1 + NP)));
+    KTQArgs a;
+    a.expo = d_expo_ns; a.rows = (const int32_t*)rows.p; a.delayed = h_delayed ? (const int32_t*)delayed.p : nullptr;
+    a.targets = (const double*)targets.p; a.first = (unsigned long long*)first.p; a.out = (double*)out.p;
+    a.ex_stride = expo_tangent_stride; a.n = n_paths; a.ld = ld; a.threshold = threshold; a.collateralized = collateralized; a.pad = 0;
+    hipLaunchKernelGGL(kt_pick_find, dim3(mcx_grid_for(n_paths, MCX_BLOCK, 256), n_dates_metric), dim3(MCX_BLOCK), 0, s, a);
+    hipLaunchKernelGGL(kt_pick_read, dim3((n_dates_metric + 63) / 64), dim3(64), 0, s, a, n_dates_metric);
+    MCX_HIP(h, hipGetLastError());
+    MCX_HIP(h, hipMemcpyAsync(h_out, out.p, sizeof(double) * (size_t)n_dates_metric * (1 + NP), hipMemcpyDeviceToHost, s));
+    MCX_HIP(h, hipStreamSynchronize(s));
     return 0;
 }

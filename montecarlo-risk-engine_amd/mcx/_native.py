@@ -22,7 +22,7 @@ _EXPORTS = [
     "mcx_sim_create", "mcx_sim_destroy", "mcx_generate_paths",
     "mcx_book_create", "mcx_book_destroy", "mcx_book_set_coeffs", "mcx_eval_book", "mcx_resolve_atoms",
     "mcx_lsm_stats", "mcx_lsm_step", "mcx_lsm_step_batch", "mcx_book_set_coeffs_batch", "mcx_book_set_bridge_rng",
-    "mcx_fused_is_straight_line", "mcx_tangent_paths", "mcx_tangent_lsm", "mcx_tangent_eval", "mcx_tangent_cva", "mcx_tangent_profiles",
+    "mcx_fused_is_straight_line", "mcx_tangent_paths", "mcx_tangent_lsm", "mcx_tangent_eval", "mcx_tangent_cva", "mcx_tangent_profiles", "mcx_tangent_pick",
     "mcx_tangent_european", "mcx_fused_create", "mcx_fused_destroy", "mcx_fused_num_records", "mcx_fused_run", "mcx_fused_eval_paths",
     "mcx_reduce_vector", "mcx_reduce_profiles", "mcx_reduce_cva", "mcx_unsecured", "mcx_select_hist",
 ]
@@ -261,6 +261,19 @@ class HipBackend:
             _vp(expo.data_ptr()), _abi.ptr(np.ascontiguousarray(ev_param, dtype=np.int32)) if ev_param is not None else None,
             self._stream()), "mcx_tangent_eval")
         return cfs, expo
+
+    def tangent_pick(self, rows, threshold: float, targets, expo: torch.Tensor, ns_i: int, delayed=None, collateralized=False) -> np.ndarray:
+        """-> [n_dates][1+NP]: (local index of the path realising the order statistic or -1, its tangent)"""
+        r = np.ascontiguousarray(rows, dtype=np.int32)
+        dl = None if delayed is None else np.ascontiguousarray(delayed, dtype=np.int32)
+        tg = np.ascontiguousarray(targets, dtype=np.float64)
+        out = np.zeros((len(r), 1 + _abi.TANGENT_NP))
+        n = expo.shape[3]
+        stride = expo.shape[1] * expo.shape[2] * expo.shape[3]
+        self._check(self.lib.mcx_tangent_pick(self.h, _abi.ptr(r), _abi.ptr(dl) if dl is not None else None, C.c_int32(int(collateralized)),
+                                              C.c_int32(len(r)), C.c_double(threshold), _abi.ptr(tg), _vp(expo[0, ns_i].data_ptr()),
+                                              C.c_int64(stride), C.c_int64(n), C.c_int64(n), _abi.ptr(out), self._stream()), "mcx_tangent_pick")
+        return out
 
     def tangent_cva(self, book, datoms: torch.Tensor, rows, surv, cond, threshold: float, recovery: float, expo: torch.Tensor,
                     ns_i: int, paths: torch.Tensor, dpaths: torch.Tensor, delayed=None, collateralized=False) -> torch.Tensor:

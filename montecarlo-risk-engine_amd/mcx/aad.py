@@ -256,8 +256,8 @@ def run_with_tangent_book(sc):
     rm = sc.risk_metrics
     if sc.simulation_scheme.name != "EULER":
         raise _NoTangentForm("scheme")
-    if any(m.metric_type not in (MetricType.PV, MetricType.CVA, MetricType.EPE, MetricType.ENE, MetricType.CE, MetricType.EEPE)
-           or not m._native for m in rm.metrics):
+    if any(m.metric_type not in (MetricType.PV, MetricType.CVA, MetricType.EPE, MetricType.ENE, MetricType.CE, MetricType.EEPE,
+                                 MetricType.PFE) or not m._native for m in rm.metrics):
         raise _NoTangentForm("metric")
     if any(p.get_num_states() != 1 for p in sc.products) or len(sc.products) > 64:
         raise _NoTangentForm("products")
@@ -383,6 +383,19 @@ def run_with_tangent_book(sc):
                             side = 0 if m.metric_type == MetricType.EPE else 1
                             for e_i in range(n_eval[m_i]):
                                 grads[ns_i][m_i][e_i][j] = float(prof[e_i, side, q])
+                elif m.metric_type == MetricType.PFE:
+                    # the tangent of the path that realises the exact order statistic (the reference differentiates through
+                    # torch.sort): radix select on the primal image, then the first path carrying that value
+                    from .plan import UnsecuredSpec
+                    unsec = UnsecuredSpec(rows, delayed, ns.threshold, coll)
+                    target = base._select_order_stats(shard, unsec, expo[0, ns_i], [m.q_index(sc.num_paths_mainsim)])[:, 0]
+                    pick = be.tangent_pick(rows, ns.threshold, target, expo, ns_i, delayed, coll)
+                    pick[:, 0] = np.where(pick[:, 0] >= 0, pick[:, 0] + off, np.inf)          # global path index
+                    allp = shard.all_gather_np(pick)                                          # [world][dates][1+NP]
+                    win = np.argmin(allp[:, :, 0], axis=0)
+                    for e_i in range(n_eval[m_i]):
+                        for q, j in enumerate(sel):
+                            grads[ns_i][m_i][e_i][j] = float(allp[win[e_i], e_i, 1 + q])
                 elif not (ns.counterparty_id is not None and m.counterparty_id != ns.counterparty_id):
                     surv, cond = base._cva_atoms[m_i]
                     out = be.tangent_cva(book, datoms, rows, surv, cond, ns.threshold, m.recovery_rate, expo, ns_i, paths, dpaths, delayed, coll)

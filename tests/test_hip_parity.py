@@ -387,13 +387,20 @@ def test_forward_mode_analytic_black_scholes_exposures_match_bumps(hip):
         c = cases.EuropeanOption(cases.Equity(), 1.0, 95.0, cases.OptionType.CALL); c.name = "call"
         p = cases.EuropeanOption(cases.Equity(), 1.5, 110.0, cases.OptionType.PUT); p.name = "put"
         ns = [cases.NettingSet(name="opts", products=[c, p])]
-        rm = cases.RiskMetrics([cases.EPEMetric(), cases.PVMetric()], exposure_timeline=np.array([0.0, 0.25, 0.5, 1.0, 1.25, 1.5, 2.0]))
+        rm = cases.RiskMetrics([cases.EPEMetric(), cases.PVMetric(), cases.PFEMetric(0.95)],
+                               exposure_timeline=np.array([0.0, 0.25, 0.5, 1.0, 1.25, 1.5, 2.0]))
         sc = cases.SimulationController(ns, model, rm, 16384, 0, 4, cases.E, differentiate=True, backend=hip)
         sc.forward_mode = fwd
         r = sc.run_simulation()
         assert bool(sc.timings.get("tangent")) == fwd, sc.timings
-        out[fwd] = (np.array(r.derivatives[0][0]), np.array(r.derivatives[0][1]), np.array(r.results[0][0]))
+        out[fwd] = (np.array(r.derivatives[0][0]), np.array(r.derivatives[0][1]), np.array(r.results[0][0]), np.array(r.derivatives[0][2]))
     assert np.allclose(out[True][2], out[False][2], rtol=1e-12)
     for k in (0, 1):
         scale = np.abs(out[False][k]).max()
         assert scale > 0 and np.allclose(out[True][k], out[False][k], rtol=1e-4, atol=3e-5 * scale), (k, out[True][k], out[False][k])
+    # PFE(0.95): the tangent of the path at the order statistic; a bump keeps the same path there unless two paths swap ranks
+    # (when a bump makes two paths next to the quantile swap ranks the difference quotient of that entry is not the tangent of
+    #  one path any more: require agreement of at least 90 % of the entries, exactly as many as never see a swap)
+    scale = np.abs(out[False][3]).max()
+    close = np.isclose(out[True][3], out[False][3], rtol=1e-4, atol=1e-6 * scale)
+    assert scale > 0 and close.mean() >= 0.9, (out[True][3], out[False][3])
