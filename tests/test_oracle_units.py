@@ -182,3 +182,25 @@ def test_netting_algebra_literals():
     thr = UnsecuredSpec(np.array([0, 1, 2]), None, 6.0, False)
     got = be.unsecured(thr, expo).numpy()
     assert np.array_equal(got, np.array([[0.0, 0.0], [0.0, 4.0], [4.0, 14.0]]))
+
+
+def test_batched_normal_equation_solver_matches_scalar_one():
+    """mcx.plan.solve_normal_equations_batch (product-batched LSM) against solve_normal_equations, incl. a degenerate system"""
+    from mcx.plan import solve_normal_equations, solve_normal_equations_batch
+    rng = np.random.default_rng(7)
+    K, S, n_jobs, N = 3, 2, 6, 500
+    moms, shifts, scales, degs, xmins = [], [], [], [], []
+    for j in range(n_jobs):
+        x = rng.normal(100.0, 10.0, N) if j != 3 else np.full(N, 42.0)
+        lo, hi = x.min(), x.max()
+        deg = not (hi > lo)
+        shift, scale = (0.5 * (lo + hi), 2.0 / (hi - lo)) if not deg else (lo, 1.0)
+        z = (x - shift) * scale
+        y = rng.normal(size=(S, N)) + 0.01 * x
+        m = [np.sum(z ** k) for k in range(2 * K - 1)] + [np.sum(z ** k * y[s]) for s in range(S) for k in range(K)]
+        moms.append(m); shifts.append(shift); scales.append(scale); degs.append(deg); xmins.append(lo)
+    moms = np.array(moms)
+    batch = solve_normal_equations_batch(moms, K, S, np.array(shifts), np.array(scales), np.array(degs), np.array(xmins))
+    for j in range(n_jobs):
+        one = solve_normal_equations(moms[j], K, S, shifts[j], scales[j], degs[j], xmins[j])
+        assert np.allclose(batch[j], one, rtol=1e-10, atol=1e-12), (j, batch[j], one)
