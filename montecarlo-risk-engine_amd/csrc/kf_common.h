@@ -1,0 +1,131 @@
+// kf_common.h — records and device helpers shared by the fused main-pass kernels (kf_fused.hip: event interpreter and
+// evaluation-from-paths pass; kf_lean.hip: the straight-line one-launch kernel).  gfx950 only.
+#pragma once
+#include "mcx_device.h"
+
+
+
+struct FAtom {             // value = a + d*x + b*exp(c0 + c1*x), x = register `reg` of the lane (reg < 0: x = 0)
+    int32_t reg, pad;
+    double a, d, b, c0, c1;
+};
+struct FTerm { double w; FAtom atom; };
+struct FEvent {
+    int32_t kind, flags;
+    int32_t term_begin, term_end;
+    int32_t coeff_off, row;
+    int32_t ns, sidx;          // netting-set slot (0..3), stateful-product slot (0..3) or -1
+    int32_t init_state, pad;
+    double strike, sign;
+    double aux[4];
+    FAtom num, x;
+};
+struct FMetricOp {             // one (netting set, metric date) pair, executed after the date's events
+    int32_t ns, m;
+    int32_t rec_profile;       // record index of relu(u) (rec+1 = -relu(-u)), -1: no profiles
+    int32_t has_cva;           // 1: m < n_dates-1 and CVA wanted
+    double threshold;
+    FAtom surv, cond;
+};
+
+struct ChunkHeader { int32_t n_ev, n_mop, n_terms, bytes; };
+
+// Straight-line record of a date whose program is the common linear-book shape (one netting set; cashflows that are an
+// affine term + <= 4 exponential terms over a pure-exponential or constant numeraire; stateless polynomial exposures; an
+// optional threshold / EPE-ENE record / CVA increment).  Such a date runs ~130 instructions of branch-light code with every
+// control field in SGPRs instead of ~500 instructions of event interpretation; any other date uses the interpreter.
+struct FastDate {
+    int32_t valid, flags;            // flags: 1 cash, 2 expo, 4 cva, 8 profile, 16 constant numeraire, 32 metric op present,
+                                     // 64: the CVA increment may use the merged discount x survival factor (m_*): no threshold,
+                                     //     no EPE / ENE record on this date
+    int32_t ni_reg, lin_reg, n_exp, x_reg, coeff_off0, coeff_off1, rec_profile, s_reg, c_reg, pad;
+    int32_t t_reg[4];
+    double ni_c0, ni_c1;             // 1/numeraire = exp(ni_c0 + ni_c1 x)   (flag 16: = ni_c0)
+    double k0, k1;                   // cash affine part k0 + k1 * reg[lin_reg]
+    double t_w[4], t_c0[4], t_c1[4];
+    double x_a, x_d;                 // explanatory x = x_a + x_d * reg[x_reg]
+    double thr;
+    double s_b, s_c0, s_c1;          // S(0,t)       = s_b exp(s_c0 + s_c1 reg[s_reg])
+    double c_a, c_b, c_c0, c_c1;     // S(t,t+) cond = c_a + c_b exp(c_c0 + c_c1 reg[c_reg])
+    double m_b, m_c0, m_n1, m_s1;    // S(0,t) / numeraire = m_b exp(m_c0 + m_n1 reg[ni_reg] + m_s1 reg[s_reg])   (flag 64)
+};
+
+struct FusedArgs {
+    K1Args k1;
+    const FastDate* __restrict__ fast;        // [n_dates]
+    const unsigned char* __restrict__ prog;   // per-date program chunks (header | events | terms | metric ops)
+    const int32_t* __restrict__ date_off;     // [n_dates+1] byte offset of each date's chunk (16-byte aligned)
+    const int32_t* __restrict__ date_row;     // [n_dates] exposure row of this timeline date or -1
+    const double* __restrict__ coeffs;
+    double* __restrict__ cfs;                 // nullable [NS][ld_out]
+    double* __restrict__ expo;                // nullable [NS][n_expo_rows][ld_out]
+    double* __restrict__ partials;            // [gridDim.x][n_rec][4]
+    int64_t ld_out;
+    int32_t n_dates, n_basis, n_ns, n_rec, n_expo_rows, n_stateful, chunk_cap, pad;
+    int32_t rec_pv[MCX_FUSED_MAX_NS];         // record index of the PV record of ns slot k, or -1
+    int32_t rec_cva[MCX_FUSED_MAX_NS];
+    double lgd[MCX_FUSED_MAX_NS];
+    int32_t init_state[MCX_FUSED_MAX_STATEFUL];
+};
+
+#define RFL(x) __builtin_amdgcn_readfirstlane(x)
+
+template <int NREG>
+__device__ __forceinline__ double f_atom(const FAtom& a, const double (&reg)[NREG])
+{
+    // the program lives in LDS, so its fields arrive in VGPRs; the CONTROL fields are made wave-uniform SGPRs
+    // (v_readfirstlane) so that selects / branches are scalar instead of exec-masked divergent code
+    const int r = RFL(a.reg), fl = RFL(a.pad);          // pad: bit0 = has exp term, bit1 = has affine term
+    const double x = r >= 0 ? reg[r] : 0.0;             // uniform dynamic index -> M0-relative VGPR read (v_movrels)
+    double v = (fl & 2) ? fma(a.d, x, a.a) : 0.0;
+    if (fl & 1) v = fma(a.b, mcx_exp(fma(a.c1, x, a.c0)), v);
+    return v;
+}
+
+// coefficients of a STATELESS product are the same for every lane: wave-uniform offset -> scalar loads (s_load through the
+// scalar cache) instead of a dependent per-lane global load with L2 latency on every exposure date
+__device__ __forceinline__ double f_poly_uniform(const double* __restrict__ coeffs, int off_vgpr, int K, double x)
+{
+    const double* __restrict__ c = coeffs + __builtin_amdgcn_readfirstlane(off_vgpr);
+    double v = 0.0, xp = 1.0;
+#pragma unroll 1
+    for (int k = 0; k < K; ++k) { v = fma(ldk(c + k), xp, v); xp *= x; }
+    return v;
+}
+
+__device__ __forceinline__ double f_poly(const double* __restrict__ c, int K, double x)
+{
+    double v = 0.0, xp = 1.0;
+#pragma unroll 1
+    for (int k = 0; k < K; ++k) { v = fma(c[k], xp, v); xp *= x; }
+    return v;
+}
+
+// LDS record area: shift[n_rec] | acc[4 waves][n_rec][2]
+__device__ __forceinline__ void f_record(double v, bool live, int rec, int n_rec, bool first_tile, double* __restrict__ lds)
+{
+    if (first_tile) {                      // block-uniform: the first path the block sees fixes the record's shift
+        __syncthreads();
+        if (threadIdx.x == 0) lds[rec] = v;
+        __syncthreads();
+    }
+    const double c = lds[rec];
+    const double d = live ? v - c : 0.0;
+    const double s1 = wave_sum(d), s2 = wave_sum(d * d);
+    if ((threadIdx.x & 63) == 0) {
+        double* acc = lds + n_rec + ((threadIdx.x >> 6) * n_rec + rec) * 2;
+        acc[0] += s1;
+        acc[1] += s2;
+    }
+}
+
+template <int NREG>
+__device__ __forceinline__ double f_regsel(int r, const double (&reg)[NREG])      // r is wave-uniform (SGPR)
+{
+    return r >= 0 ? reg[r] : 0.0;       // uniform dynamic index -> v_movrels (M0-relative VGPR read), no select chain
+}
+
+
+// kf_lean.hip: launches the straight-line one-launch kernel for a book whose every date has a FastDate record; returns the
+// grid size (= number of per-block partial records written to a.partials), or -1 when (slots, z) has no instantiation
+int mcx_launch_kf_lean(const FusedArgs& a, const mcx_sim_desc& sd, int n_cu, bool inject, hipStream_t s);

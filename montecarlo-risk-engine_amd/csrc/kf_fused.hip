@@ -10,7 +10,7 @@
 // Block-level reduction design: per record r the block keeps a shift c_r (value of the first path it sees) and, per wave,
 // the pair (sum (x-c), sum (x-c)^2) in LDS; every date costs one wave64 shuffle reduction per record.  Blocks write one
 // (n, c, s1, s2) record each; a tiny second kernel merges blocks with Chan's update (deterministic, no float atomics).
-#include "mcx_device.h"
+#include "kf_common.h"
 
 #include <algorithm>
 #include <type_traits>
@@ -18,130 +18,6 @@
 #include <cstdlib>
 
 namespace {
-
-struct FAtom {             // value = a + d*x + b*exp(c0 + c1*x), x = register `reg` of the lane (reg < 0: x = 0)
-    int32_t reg, pad;
-    double a, d, b, c0, c1;
-};
-struct FTerm { double w; FAtom atom; };
-struct FEvent {
-    int32_t kind, flags;
-    int32_t term_begin, term_end;
-    int32_t coeff_off, row;
-    int32_t ns, sidx;          // netting-set slot (0..3), stateful-product slot (0..3) or -1
-    int32_t init_state, pad;
-    double strike, sign;
-    double aux[4];
-    FAtom num, x;
-};
-struct FMetricOp {             // one (netting set, metric date) pair, executed after the date's events
-    int32_t ns, m;
-    int32_t rec_profile;       // record index of relu(u) (rec+1 = -relu(-u)), -1: no profiles
-    int32_t has_cva;           // 1: m < n_dates-1 and CVA wanted
-    double threshold;
-    FAtom surv, cond;
-};
-
-struct ChunkHeader { int32_t n_ev, n_mop, n_terms, bytes; };
-
-// Straight-line record of a date whose program is the common linear-book shape (one netting set; cashflows that are an
-// affine term + <= 4 exponential terms over a pure-exponential or constant numeraire; stateless polynomial exposures; an
-// optional threshold / EPE-ENE record / CVA increment).  Such a date runs ~130 instructions of branch-light code with every
-// control field in SGPRs instead of ~500 instructions of event interpretation; any other date uses the interpreter.
-struct FastDate {
-    int32_t valid, flags;            // flags: 1 cash, 2 expo, 4 cva, 8 profile, 16 constant numeraire, 32 metric op present
-    int32_t ni_reg, lin_reg, n_exp, x_reg, coeff_off0, coeff_off1, rec_profile, s_reg, c_reg, pad;
-    int32_t t_reg[4];
-    double ni_c0, ni_c1;             // 1/numeraire = exp(ni_c0 + ni_c1 x)   (flag 16: = ni_c0)
-    double k0, k1;                   // cash affine part k0 + k1 * reg[lin_reg]
-    double t_w[4], t_c0[4], t_c1[4];
-    double x_a, x_d;                 // explanatory x = x_a + x_d * reg[x_reg]
-    double thr;
-    double s_b, s_c0, s_c1;          // S(0,t)       = s_b exp(s_c0 + s_c1 reg[s_reg])
-    double c_a, c_b, c_c0, c_c1;     // S(t,t+) cond = c_a + c_b exp(c_c0 + c_c1 reg[c_reg])
-};
-
-struct FusedArgs {
-    K1Args k1;
-    const FastDate* __restrict__ fast;        // [n_dates]
-    const unsigned char* __restrict__ prog;   // per-date program chunks (header | events | terms | metric ops)
-    const int32_t* __restrict__ date_off;     // [n_dates+1] byte offset of each date's chunk (16-byte aligned)
-    const int32_t* __restrict__ date_row;     // [n_dates] exposure row of this timeline date or -1
-    const double* __restrict__ coeffs;
-    double* __restrict__ cfs;                 // nullable [NS][ld_out]
-    double* __restrict__ expo;                // nullable [NS][n_expo_rows][ld_out]
-    double* __restrict__ partials;            // [gridDim.x][n_rec][4]
-    int64_t ld_out;
-    int32_t n_dates, n_basis, n_ns, n_rec, n_expo_rows, n_stateful, chunk_cap, pad;
-    int32_t rec_pv[MCX_FUSED_MAX_NS];         // record index of the PV record of ns slot k, or -1
-    int32_t rec_cva[MCX_FUSED_MAX_NS];
-    double lgd[MCX_FUSED_MAX_NS];
-    int32_t init_state[MCX_FUSED_MAX_STATEFUL];
-};
-
-#define RFL(x) __builtin_amdgcn_readfirstlane(x)
-
-template <int NREG>
-__device__ __forceinline__ double f_atom(const FAtom& a, const double (&reg)[NREG])
-{
-    // the program lives in LDS, so its fields arrive in VGPRs; the CONTROL fields are made wave-uniform SGPRs
-    // (v_readfirstlane) so that selects / branches are scalar instead of exec-masked divergent code
-    const int r = RFL(a.reg), fl = RFL(a.pad);          // pad: bit0 = has exp term, bit1 = has affine term
-    const double x = r >= 0 ? reg[r] : 0.0;             // uniform dynamic index -> M0-relative VGPR read (v_movrels)
-    double v = (fl & 2) ? fma(a.d, x, a.a) : 0.0;
-    if (fl & 1) v = fma(a.b, mcx_exp(fma(a.c1, x, a.c0)), v);
-    return v;
-}
-
-// coefficients of a STATELESS product are the same for every lane: wave-uniform offset -> scalar loads (s_load through the
-// scalar cache) instead of a dependent per-lane global load with L2 latency on every exposure date
-__device__ __forceinline__ double f_poly_uniform(const double* __restrict__ coeffs, int off_vgpr, int K, double x)
-{
-    const double* __restrict__ c = coeffs + __builtin_amdgcn_readfirstlane(off_vgpr);
-    double v = 0.0, xp = 1.0;
-#pragma unroll 1
-    for (int k = 0; k < K; ++k) { v = fma(ldk(c + k), xp, v); xp *= x; }
-    return v;
-}
-
-__device__ __forceinline__ double f_poly(const double* __restrict__ c, int K, double x)
-{
-    double v = 0.0, xp = 1.0;
-#pragma unroll 1
-    for (int k = 0; k < K; ++k) { v = fma(c[k], xp, v); xp *= x; }
-    return v;
-}
-
-// LDS record area: shift[n_rec] | acc[4 waves][n_rec][2]
-__device__ __forceinline__ void f_record(double v, bool live, int rec, int n_rec, bool first_tile, double* __restrict__ lds)
-{
-    if (first_tile) {                      // block-uniform: the first path the block sees fixes the record's shift
-        __syncthreads();
-        if (threadIdx.x == 0) lds[rec] = v;
-        __syncthreads();
-    }
-    const double c = lds[rec];
-    const double d = live ? v - c : 0.0;
-    const double s1 = wave_sum(d), s2 = wave_sum(d * d);
-    if ((threadIdx.x & 63) == 0) {
-        double* acc = lds + n_rec + ((threadIdx.x >> 6) * n_rec + rec) * 2;
-        acc[0] += s1;
-        acc[1] += s2;
-    }
-}
-
-template <int NREG>
-__device__ __forceinline__ double f_regsel(int r, const double (&reg)[NREG])      // r is wave-uniform (SGPR)
-{
-#ifdef MCX_REGSEL_CHAIN
-    double x = 0.0;
-#pragma unroll
-    for (int q = 0; q < NREG; ++q) x = (r == q) ? reg[q] : x;
-    return x;
-#else
-    return r >= 0 ? reg[r] : 0.0;       // uniform dynamic index -> v_movrels (M0-relative VGPR read), no select chain
-#endif
-}
 
 // straight-line evaluation of a FastDate (see the struct); returns false when the date must be interpreted
 template <int NSLOT, int SIG, int NNS, bool STORE, bool ALL_FAST>
@@ -151,9 +27,6 @@ __device__ __forceinline__ bool kf_fast_date(const FusedArgs& a, int t, int64_t 
     constexpr int NREG = 2 * NSLOT;
     if (NNS != 1) return false;
     if (!ALL_FAST && ldk(&a.fast[t].valid) == 0) return false;
-#ifdef MCX_DBG_NODATE          // timing experiment only: skip the date program
-    return true;
-#endif
     const FastDate* __restrict__ fp = a.fast + t;                // every field is a scalar load at its point of use
 #define FD(x) ldk(&fp->x)
     const K1Args& k = a.k1;
@@ -325,15 +198,6 @@ __device__ __forceinline__ void kf_on_date(const FusedArgs& a, int t, int64_t i,
     }
 }
 
-#ifndef MCX_KF_WAVES
-#define MCX_KF_WAVES 0     // 0: let the register allocator decide; n: cap VGPRs for >= n waves/SIMD (tuning knob)
-#endif
-#if MCX_KF_WAVES > 0
-#define MCX_KF_ATTR __attribute__((amdgpu_waves_per_eu(MCX_KF_WAVES, 8)))
-#else
-#define MCX_KF_ATTR
-#endif
-
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // NNS = compile-time bound on netting sets (1 or MCX_FUSED_MAX_NS), NST = bound on exercise products (0 -> none).
@@ -479,7 +343,7 @@ __device__ __forceinline__ void kf_body(const FusedArgs& a)
 }
 
 template <int NSLOT, int NZ, bool INJECT, int SIG, int NNS, int NST, int NPF, bool SIMULATE>
-__global__ __launch_bounds__(MCX_BLOCK) MCX_KF_ATTR void kf_fused(const FusedArgs a)
+__global__ __launch_bounds__(MCX_BLOCK) void kf_fused(const FusedArgs a)
 {
     kf_body<NSLOT, NZ, INJECT, SIG, NNS, NST, NPF, SIMULATE>(a);
 }
@@ -536,8 +400,7 @@ void launch_kf(const FusedArgs& a, int grid, size_t lds, int npf, bool inject, b
     const bool one_ns = a.n_ns == 1, no_state = a.n_stateful == 0;
 #define MCX_KF(INJ, NNS, NST, NPF) do { if (simulate) hipLaunchKernelGGL((kf_fused<NSLOT, NZ, INJ, SIG, NNS, NST, NPF, true>), dim3(grid), dim3(MCX_BLOCK), lds, s, a); \
         else if (!INJ) hipLaunchKernelGGL((kf_fused<NSLOT, NZ, false, SIG, NNS, NST, NPF, false>), dim3(grid), dim3(MCX_BLOCK), lds, s, a); } while (0)
-#define MCX_KF_LEAN(INJ) do { if (simulate) hipLaunchKernelGGL((kf_fused_lean<NSLOT, NZ, INJ, SIG, true>), dim3(grid), dim3(MCX_BLOCK), lds, s, a); \
-        else if (!INJ) hipLaunchKernelGGL((kf_fused_lean<NSLOT, NZ, false, SIG, false>), dim3(grid), dim3(MCX_BLOCK), lds, s, a); } while (0)
+#define MCX_KF_LEAN(INJ) do { if (!simulate && !INJ) hipLaunchKernelGGL((kf_fused_lean<NSLOT, NZ, false, SIG, false>), dim3(grid), dim3(MCX_BLOCK), lds, s, a); } while (0)
 #define MCX_KF_NPF(INJ, NNS, NST) do { if (npf < 0 && NNS == 1 && NST == 0) MCX_KF_LEAN(INJ); else if (npf == 1) MCX_KF(INJ, NNS, NST, 1); else if (npf == 2) MCX_KF(INJ, NNS, NST, 2); else MCX_KF(INJ, NNS, NST, 0); } while (0)
     if (inject) {
         if (one_ns && no_state) MCX_KF_NPF(true, 1, 0);
@@ -695,7 +558,7 @@ extern "C" int mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_boo
 
     // straight-line records for dates of the linear-book shape (FastDate); such dates need no interpreted chunk
     std::vector<FastDate> fast(T);
-    const bool fast_dates_enabled = d->n_netting_sets == 1 && getenv("MCX_NO_FAST_DATES") == nullptr;     // (env: A/B timing knob)
+    const bool fast_dates_enabled = d->n_netting_sets == 1;
     for (int t = 0; t < T; ++t) {
         FastDate fd;
         memset(&fd, 0, sizeof(fd));
@@ -752,17 +615,22 @@ extern "C" int mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_boo
             }
         }
         if (okf && !num && !mop_by_date[t].empty()) { fd.flags |= 16; fd.ni_c0 = 1.0; }      // metric op on an empty date
+        // a state reference that is absent (reg < 0) becomes register 0 with a zero coefficient: the kernels may then index the
+        // lane's state registers without a range test
+        auto bind = [](int32_t& r, double& coef) { if (r < 0) { r = 0; coef = 0.0; } };
+        bind(fd.ni_reg, fd.ni_c1); bind(fd.lin_reg, fd.k1); bind(fd.x_reg, fd.x_d); bind(fd.s_reg, fd.s_c1); bind(fd.c_reg, fd.c_c1);
+        for (int j = 0; j < 4; ++j) bind(fd.t_reg[j], fd.t_c1[j]);
+        // merged discount x survival factor of the CVA increment: relu(p / N) S (1 - Sc) = relu(p) (S / N) (1 - Sc) when the date
+        // has no threshold and records no EPE / ENE profile: one exponential instead of two
+        if (okf && (fd.flags & 4) && !(fd.flags & 8) && fd.thr == 0.0) {
+            fd.flags |= 64;
+            if (fd.flags & 16) { fd.m_b = fd.s_b * fd.ni_c0; fd.m_c0 = fd.s_c0; fd.m_n1 = 0.0; }
+            else { fd.m_b = fd.s_b; fd.m_c0 = fd.s_c0 + fd.ni_c0; fd.m_n1 = fd.ni_c1; }
+            fd.m_s1 = fd.s_c1;
+        }
         fd.valid = okf ? 1 : 0;
         fast[t] = fd;
     }
-    if (getenv("MCX_FUSED_DEBUG")) {
-        int nf = 0;
-        for (int t = 0; t < T; ++t) nf += fast[t].valid;
-        fprintf(stderr, "[mcx] fused program: %d of %d dates straight-line\n", nf, T);
-        for (int t = 0; t < T && t < 4; ++t)
-            fprintf(stderr, "[mcx]  date %d: valid %d flags %d n_ev %zu n_mop %zu n_exp %d\n", t, fast[t].valid, fast[t].flags, by_date[t].size(), mop_by_date[t].size(), fast[t].n_exp);
-    }
-
     // per-date program chunks: header | events | terms | metric ops, 16-byte aligned
     std::vector<unsigned char> prog;
     std::vector<int32_t> date_off(T + 1, 0);
@@ -841,30 +709,37 @@ static int fused_run_impl(mcx_handle* h, const mcx_fused* f, bool simulate, uint
     a.n_expo_rows = f->n_expo_rows; a.n_stateful = f->n_stateful;
     for (int k = 0; k < MCX_FUSED_MAX_NS; ++k) { a.rec_pv[k] = f->rec_pv[k]; a.rec_cva[k] = f->rec_cva[k]; a.lgd[k] = f->lgd[k]; }
     for (int k = 0; k < MCX_FUSED_MAX_STATEFUL; ++k) a.init_state[k] = f->init_state[k];
-    const int64_t tiles = (n_paths + MCX_BLOCK - 1) / MCX_BLOCK;
-    int grid = (int)std::min<int64_t>(tiles, 2048);
-    // keep the tiles-per-block count integral when possible (equal work per block)
-    if (tiles > 2048) { int per = (int)((tiles + 2047) / 2048); grid = (int)((tiles + per - 1) / per); }
-    const size_t lds = sizeof(double) * (size_t)((9 * f->n_rec + 1) & ~1) + (size_t)4 * f->chunk_cap;
     hipStream_t s = (hipStream_t)stream;
     const bool inj = d_inject_z != nullptr;
-    switch (mcx_sim_signature(sd)) {
-    case SIG_VAS_CIR_E: launch_kf<2, 2, SIG_VAS_CIR_E>(a, grid, lds, f->npf, inj, simulate, s); break;
-    case SIG_BS_A: launch_kf<1, 1, SIG_BS_A>(a, grid, lds, f->npf, inj, simulate, s); break;
-    case SIG_BS_E: launch_kf<1, 1, SIG_BS_E>(a, grid, lds, f->npf, inj, simulate, s); break;
-    case SIG_HESTON_QE: launch_kf<1, 2, SIG_HESTON_QE>(a, grid, lds, f->npf, inj, simulate, s); break;
-    case SIG_HESTON_E: launch_kf<1, 2, SIG_HESTON_E>(a, grid, lds, f->npf, inj, simulate, s); break;
-    case SIG_VAS_E: launch_kf<1, 1, SIG_VAS_E>(a, grid, lds, f->npf, inj, simulate, s); break;
-    case SIG_VAS_A: launch_kf<1, 1, SIG_VAS_A>(a, grid, lds, f->npf, inj, simulate, s); break;
-    case SIG_BS_VAS_CIRDET_E: launch_kf<3, 3, SIG_BS_VAS_CIRDET_E>(a, grid, lds, f->npf, inj, simulate, s); break;
-    default:
-        switch (sd.n_slots * 16 + sd.n_z) {
-        case 1 * 16 + 1: launch_kf<1, 1, SIG_GENERIC>(a, grid, lds, f->npf, inj, simulate, s); break;
-        case 1 * 16 + 2: launch_kf<1, 2, SIG_GENERIC>(a, grid, lds, f->npf, inj, simulate, s); break;
-        case 2 * 16 + 2: launch_kf<2, 2, SIG_GENERIC>(a, grid, lds, f->npf, inj, simulate, s); break;
-        case 3 * 16 + 3: launch_kf<3, 3, SIG_GENERIC>(a, grid, lds, f->npf, inj, simulate, s); break;
-        case 4 * 16 + 4: launch_kf<4, 4, SIG_GENERIC>(a, grid, lds, f->npf, inj, simulate, s); break;
-        default: MCX_FAIL(h, MCX_E_NOT_FUSABLE, "not fusable: (slots=%d, z=%d) has no fused instantiation", sd.n_slots, sd.n_z);
+    int grid;
+    if (simulate && f->npf < 0) {
+        // every date is a straight-line record: the two-paths-per-lane kernel of kf_lean.hip
+        grid = mcx_launch_kf_lean(a, sd, h->n_cu, inj, s);
+        if (grid < 0) MCX_FAIL(h, MCX_E_NOT_FUSABLE, "not fusable: (slots=%d, z=%d) has no fused instantiation", sd.n_slots, sd.n_z);
+    } else {
+        const int64_t tiles = (n_paths + MCX_BLOCK - 1) / MCX_BLOCK;
+        grid = (int)std::min<int64_t>(tiles, 2048);
+        // keep the tiles-per-block count integral when possible (equal work per block)
+        if (tiles > 2048) { int per = (int)((tiles + 2047) / 2048); grid = (int)((tiles + per - 1) / per); }
+        const size_t lds = sizeof(double) * (size_t)((9 * f->n_rec + 1) & ~1) + (size_t)4 * f->chunk_cap;
+        switch (mcx_sim_signature(sd)) {
+        case SIG_VAS_CIR_E: launch_kf<2, 2, SIG_VAS_CIR_E>(a, grid, lds, f->npf, inj, simulate, s); break;
+        case SIG_BS_A: launch_kf<1, 1, SIG_BS_A>(a, grid, lds, f->npf, inj, simulate, s); break;
+        case SIG_BS_E: launch_kf<1, 1, SIG_BS_E>(a, grid, lds, f->npf, inj, simulate, s); break;
+        case SIG_HESTON_QE: launch_kf<1, 2, SIG_HESTON_QE>(a, grid, lds, f->npf, inj, simulate, s); break;
+        case SIG_HESTON_E: launch_kf<1, 2, SIG_HESTON_E>(a, grid, lds, f->npf, inj, simulate, s); break;
+        case SIG_VAS_E: launch_kf<1, 1, SIG_VAS_E>(a, grid, lds, f->npf, inj, simulate, s); break;
+        case SIG_VAS_A: launch_kf<1, 1, SIG_VAS_A>(a, grid, lds, f->npf, inj, simulate, s); break;
+        case SIG_BS_VAS_CIRDET_E: launch_kf<3, 3, SIG_BS_VAS_CIRDET_E>(a, grid, lds, f->npf, inj, simulate, s); break;
+        default:
+            switch (sd.n_slots * 16 + sd.n_z) {
+            case 1 * 16 + 1: launch_kf<1, 1, SIG_GENERIC>(a, grid, lds, f->npf, inj, simulate, s); break;
+            case 1 * 16 + 2: launch_kf<1, 2, SIG_GENERIC>(a, grid, lds, f->npf, inj, simulate, s); break;
+            case 2 * 16 + 2: launch_kf<2, 2, SIG_GENERIC>(a, grid, lds, f->npf, inj, simulate, s); break;
+            case 3 * 16 + 3: launch_kf<3, 3, SIG_GENERIC>(a, grid, lds, f->npf, inj, simulate, s); break;
+            case 4 * 16 + 4: launch_kf<4, 4, SIG_GENERIC>(a, grid, lds, f->npf, inj, simulate, s); break;
+            default: MCX_FAIL(h, MCX_E_NOT_FUSABLE, "not fusable: (slots=%d, z=%d) has no fused instantiation", sd.n_slots, sd.n_z);
+            }
         }
     }
     MCX_HIP(h, hipGetLastError());

@@ -1,0 +1,349 @@
+// kf_lean.hip — the one-launch main pass for books whose every timeline date compiled to a straight-line FastDate record
+// (kf_common.h): Philox + Box-Muller + Cholesky + SDE sub-steps, the date's cashflows / regression exposure / threshold /
+// EPE-ENE records / CVA increment, and the block accumulators — nothing materialised in HBM.
+//
+// Reference dataflow replaced: controller/controller.py:677-694 (generate_paths -> resolve_requests -> evaluate_products ->
+// metric reductions) for the linear-book shape (bond.py:115-214, swap.py:129-172 cashflows; controller.py:385-471 exposures;
+// cva_metric.py:23-100; epe/ene_metric.py).
+//
+// Mapping to the hardware (MI355X: 256 CUs x 4 SIMDs, f64 VALU issue is the bound of this kernel — MI355X_MICROARCH.md):
+//   * TWO paths per lane (PPL = 2): a lane carries two independent RNG / SDE / payoff dependency chains, so 4 resident
+//     waves per SIMD give the issue parallelism of 8 and every wave-uniform cost (scalar table loads, SALU control, the
+//     date record) is paid once per 128 paths instead of once per 64;
+//   * the launch is sized to the residency the code object guarantees: __launch_bounds__(256, 4) => <= 128 VGPRs, 4 blocks
+//     per CU for any SGPR count (800 / (ceil(sgpr/16)*16 + 16) >= 4), so grid = 4 x CUs blocks are all co-resident and the
+//     path tiles (512 paths per block-tile) are dealt round-robin: 2^20 paths = 2048 tiles = exactly two rounds, no
+//     partially filled last round (the round-1 kernel ran 8 waves per SIMD slot on a 6-7 wave residency: one round in
+//     eight at a fraction of the issue rate);
+//   * scalar state is REGION-LOCAL: every code region (tile prologue, one run of sub-steps, a date block, tile epilogue)
+//     reads the kernel arguments, the FastDate record and the polynomial coefficient tables through a pointer that carries
+//     a "region zero" (mcx_math.h), i.e. as scalar loads at the point of use.  Left alone, the backend loads all ~100
+//     argument dwords in the prologue, keeps them live through every loop and spills them to VGPR lanes; each reload is a
+//     v_readlane — a VALU instruction, the pipe this kernel is bound by (the round-1 kernel carried 82 such spills).
+#include "kf_common.h"
+
+namespace {
+
+#define FD(x) ldk(&fp->x)
+
+// the kernel arguments as seen from one code region: the kernarg segment (explicit arguments start at offset 0) behind a
+// region zero
+typedef const MCX_KONST FusedArgs KArgs;
+__device__ __forceinline__ KArgs& kargs_region(int z)
+{
+    return *(KArgs*)((const MCX_KONST char*)__builtin_amdgcn_kernarg_segment_ptr() + z);
+}
+
+// polynomial in the raw explanatory variable with wave-uniform coefficients (scalar loads); K == 3 is the default
+// PolyomialRegression(degree=2) of the reference (controller.py:35)
+template <int PPL>
+__device__ __forceinline__ void lean_poly_add(const double* __restrict__ c, int K, const double (&x)[PPL], double (&p)[PPL])
+{
+    if (K == 3) {
+        const double c0 = ldk(c), c1 = ldk(c + 1), c2 = ldk(c + 2);
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) p[q] += fma(fma(c2, x[q], c1), x[q], c0);
+    } else {
+        double v[PPL];
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) v[q] = 0.0;
+#pragma unroll 1
+        for (int k = K - 1; k >= 0; --k) {
+            const double ck = ldk(c + k);
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) v[q] = fma(v[q], x[q], ck);
+        }
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) p[q] += v[q];
+    }
+}
+
+// LDS record area: shift[n_rec] | acc[4 waves][n_rec][2]   (layout of f_record, kf_common.h)
+template <int PPL>
+__device__ __forceinline__ void lean_record(const double (&v)[PPL], const bool (&live)[PPL], int rec, int n_rec, bool first_tile,
+                                            double* __restrict__ lds)
+{
+    if (first_tile) {                      // block-uniform: the first path the block sees fixes the record's shift
+        __syncthreads();
+        if (threadIdx.x == 0) lds[rec] = v[0];
+        __syncthreads();
+    }
+    const double c = lds[rec];
+    double d1 = 0.0, d2 = 0.0;
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) {
+        const double d = live[q] ? v[q] - c : 0.0;
+        d1 += d;
+        d2 = fma(d, d, d2);
+    }
+    const double s1 = wave_sum(d1), s2 = wave_sum(d2);
+    if ((threadIdx.x & 63) == 0) {
+        double* acc = lds + n_rec + ((threadIdx.x >> 6) * n_rec + rec) * 2;
+        acc[0] += s1;
+        acc[1] += s2;
+    }
+}
+
+template <int NSLOT, int SIG, int PPL>
+__device__ __forceinline__ void lean_date(int t, const int64_t (&i)[PPL], const bool (&live)[PPL], bool first_tile,
+                                          double* __restrict__ lds, const double (&reg)[PPL][2 * NSLOT], double (&cfs)[PPL], double (&cva)[PPL])
+{
+    // (state registers are indexed by wave-uniform record fields: M0-relative VGPR reads; mcx_fused_create binds an absent
+    // reference to register 0 with a zero coefficient, so no range test is needed)
+    const int zd = mcx_region_zero();                  // arguments, date record and exp coefficients: live in this block only
+    KArgs& a = kargs_region(zd);
+    const FastDate* __restrict__ fp = a.fast + t;
+    const auto& k = a.k1;
+    const mcx_exp_coef ec = mcx_exp_load(zd);
+    if (k.paths) {
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) if (live[q]) sim_store_state<NSLOT, SIG>(k, t, i[q], reg[q]);
+    }
+    const int flags = FD(flags);
+    // cashflows feed the PV record / the cashflow output only; a CVA / exposure-profile run skips them
+    const bool want_cash = (flags & 1) && (a.cfs != nullptr || a.rec_pv[0] >= 0);
+    // CVA-only date without threshold: relu(p / N) S (1 - Sc) = relu(p) (S / N) (1 - Sc), one exponential for S / N
+    const bool merged = (flags & 64) && !want_cash && a.expo == nullptr;
+    double inv[PPL];
+    if (!merged) {
+        if (flags & 16) {
+            const double c = FD(ni_c0);
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) inv[q] = c;
+        } else {
+            const double c0 = FD(ni_c0), c1 = FD(ni_c1);
+            const int r = FD(ni_reg);
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) inv[q] = mcx_exp(fma(c1, reg[q][r], c0), ec);
+        }
+    }
+    if (want_cash) {
+        const double k0 = FD(k0), k1 = FD(k1);
+        const int lr = FD(lin_reg), n_exp = FD(n_exp);
+        double val[PPL];
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) val[q] = fma(k1, reg[q][lr], k0);
+#pragma unroll 1
+        for (int j = 0; j < n_exp; ++j) {
+            const double w = FD(t_w[j]), c0 = FD(t_c0[j]), c1 = FD(t_c1[j]);
+            const int r = FD(t_reg[j]);
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) val[q] = fma(w, mcx_exp(fma(c1, reg[q][r], c0), ec), val[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) cfs[q] = fma(val[q], inv[q], cfs[q]);
+    }
+    double p[PPL];
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) p[q] = 0.0;
+    if (flags & 2) {
+        const double xa = FD(x_a), xd = FD(x_d);
+        const int xr = FD(x_reg), off0 = FD(coeff_off0), off1 = FD(coeff_off1);
+        double x[PPL];
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) x[q] = fma(xd, reg[q][xr], xa);
+        if (off0 >= 0) lean_poly_add<PPL>(a.coeffs + off0, a.n_basis, x, p);
+        if (off1 >= 0) lean_poly_add<PPL>(a.coeffs + off1, a.n_basis, x, p);
+    }
+    // survival probability over the next interval, conditional on the credit state (cva_metric.py:66-89)
+    auto cond_surv = [&](double (&cs)[PPL]) {
+        const double ca = FD(c_a), cb = FD(c_b);
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) cs[q] = ca;
+        if (cb != 0.0) {
+            const double cc0 = FD(c_c0), cc1 = FD(c_c1);
+            const int cr = FD(c_reg);
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) cs[q] = fma(cb, mcx_exp(fma(cc1, reg[q][cr], cc0), ec), ca);
+        }
+    };
+    if (merged) {
+        const double mb = FD(m_b), mc0 = FD(m_c0), mn1 = FD(m_n1), ms1 = FD(m_s1);
+        const int nr = FD(ni_reg), sr = FD(s_reg);
+        double w[PPL], cs[PPL];
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) w[q] = mb * mcx_exp(fma(ms1, reg[q][sr], fma(mn1, reg[q][nr], mc0)), ec);
+        cond_surv(cs);
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) cva[q] = fma(fmax(p[q], 0.0), w[q] * (1.0 - cs[q]), cva[q]);
+        return;
+    }
+    double e[PPL];
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) e[q] = p[q] * inv[q];
+    if (a.expo) {
+        const int row = ldk(a.date_row + t);
+        if (row >= 0) {
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) if (live[q]) a.expo[(int64_t)row * a.ld_out + i[q]] = e[q];
+        }
+    }
+    if (flags & 32) {
+        const double thr = FD(thr);
+        double u[PPL];
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) u[q] = dev_thr(e[q], thr);
+        if (flags & 8) {
+            const int rp = FD(rec_profile);
+            double up[PPL], un[PPL];
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) { up[q] = fmax(u[q], 0.0); un[q] = fmin(u[q], 0.0); }
+            lean_record<PPL>(up, live, rp, a.n_rec, first_tile, lds);
+            lean_record<PPL>(un, live, rp + 1, a.n_rec, first_tile, lds);
+        }
+        if (flags & 4) {
+            const double sb = FD(s_b), sc0 = FD(s_c0), sc1 = FD(s_c1);
+            const int sr = FD(s_reg);
+            double sp[PPL], cs[PPL];
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) sp[q] = sb * mcx_exp(fma(sc1, reg[q][sr], sc0), ec);
+            cond_surv(cs);
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) cva[q] = fma(fmax(u[q], 0.0), sp[q] * (1.0 - cs[q]), cva[q]);
+        }
+    }
+}
+
+#ifndef MCX_LEAN_PPL          // (tools/build_variants.sh builds A/B variants of this file; the product uses the defaults)
+#define MCX_LEAN_PPL 2
+#define MCX_LEAN_WAVES 4
+#endif
+template <int NSLOT, int NZ, bool INJECT, int SIG, int PPL>
+__global__ __launch_bounds__(MCX_BLOCK, MCX_LEAN_WAVES) void kf_lean(const FusedArgs)      // read through kargs_region(), never by name
+{
+    constexpr int NREG = 2 * NSLOT;
+    constexpr int TILE = MCX_BLOCK * PPL;
+    extern __shared__ double lds[];
+    KArgs& a0 = kargs_region(0);
+    const int n_rec = a0.n_rec;
+    const int64_t n = a0.k1.n;
+    for (int q = threadIdx.x; q < 9 * n_rec; q += MCX_BLOCK) lds[q] = 0.0;
+    __shared__ double bm_lds[INJECT ? 2 : MCX_BM_LDS_DOUBLES];      // Box-Muller lookup tables
+    const double* tab = nullptr;
+    if (!INJECT) { mcx_bm_load(bm_lds); tab = bm_lds; }
+    __syncthreads();
+    const int64_t tiles = (n + TILE - 1) / TILE;
+    double n_block = 0.0;
+
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const bool first_tile = tile == (int64_t)blockIdx.x;
+        int64_t i[PPL];
+        bool live[PPL];
+        uint64_t path[PPL];
+        double reg[PPL][NREG];                         // reg[q][2s], reg[q][2s+1] = state of slot s of the lane's q-th path
+        double cfs[PPL], cva[PPL];
+        int n_init, n_steps;
+        {
+            KArgs& a = kargs_region(mcx_region_zero());          // tile prologue
+            const auto& k = a.k1;
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) {
+                const int64_t i_raw = tile * TILE + q * MCX_BLOCK + threadIdx.x;
+                live[q] = i_raw < n;
+                i[q] = live[q] ? i_raw : n - 1;        // dead lanes shadow the last path (no stores, no contribution)
+                path[q] = k.path_offset + (uint64_t)i[q];
+                sim_init_state<NSLOT, SIG>(k, reg[q]);
+                cfs[q] = 0.0; cva[q] = 0.0;
+            }
+            const int64_t rest = n - tile * TILE;
+            n_block += (double)(rest < TILE ? rest : TILE);
+            n_init = k.n_initial_store; n_steps = k.n_steps;
+        }
+        // ONE date call site: the dates that hold the initial state come first (their sub-step run is empty), then
+        // alternately a run of sub-steps up to the next timeline date and that date's program
+        int step = 0, t_init = 0;
+#pragma unroll 1
+        while (true) {
+            const bool init = t_init < n_init;
+            if (!init && step >= n_steps) break;
+            int st = init ? t_init : -1;
+            t_init += init ? 1 : 0;
+            {
+                const int zr = mcx_region_zero();       // arguments, Philox key schedule, Box-Muller coefficients of this run
+                const auto& k = kargs_region(zr).k1;
+                const uint64_t seed = k.seed;
+                const mcx_bm_coef bc = mcx_bm_coef_load(zr);
+#pragma unroll 1
+                while (st < 0 && step < n_steps) {
+#pragma unroll
+                    for (int q = 0; q < PPL; ++q) sim_substep<NSLOT, NZ, INJECT, SIG>(k, step, path[q], i[q], reg[q], tab, seed, bc);
+                    st = ldk(&k.steps[step].store_idx);
+                    ++step;
+                }
+            }
+            if (st >= 0) lean_date<NSLOT, SIG, PPL>(st, i, live, first_tile, lds, reg, cfs, cva);
+        }
+        {
+            KArgs& a = kargs_region(mcx_region_zero());          // tile epilogue: per-path quantities
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) if (a.cfs && live[q]) a.cfs[i[q]] = cfs[q];
+            if (a.rec_pv[0] >= 0) lean_record<PPL>(cfs, live, a.rec_pv[0], n_rec, first_tile, lds);
+            if (a.rec_cva[0] >= 0) {
+                const double lgd = a.lgd[0];
+                double cc[PPL];
+#pragma unroll
+                for (int q = 0; q < PPL; ++q) cc[q] = cva[q] * lgd;
+                lean_record<PPL>(cc, live, a.rec_cva[0], n_rec, first_tile, lds);
+            }
+        }
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < n_rec; r += MCX_BLOCK) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int w = 0; w < 4; ++w) { s1 += lds[n_rec + (w * n_rec + r) * 2]; s2 += lds[n_rec + (w * n_rec + r) * 2 + 1]; }
+        double* dst = a0.partials + ((int64_t)blockIdx.x * n_rec + r) * 4;
+        dst[0] = n_block; dst[1] = lds[r]; dst[2] = s1; dst[3] = s2;
+    }
+}
+
+#undef FD
+
+template <int NSLOT, int NZ, int SIG>
+void launch_lean(const FusedArgs& a, int n_cu, bool inject, hipStream_t s, int* grid_out)
+{
+    constexpr int PPL = MCX_LEAN_PPL;
+    const int64_t tiles = (a.k1.n + MCX_BLOCK * PPL - 1) / (MCX_BLOCK * PPL);
+    const int64_t resident = (int64_t)MCX_LEAN_WAVES * n_cu;    // __launch_bounds__(256, 4): 4 blocks per CU, all co-resident
+    int grid = (int)tiles;
+    if (tiles > resident) {                                     // equal number of tiles per block whenever the count divides
+        const int64_t per = (tiles + resident - 1) / resident;
+        grid = (int)((tiles + per - 1) / per);
+    }
+    const size_t lds = sizeof(double) * (size_t)((9 * a.n_rec + 1) & ~1);
+    if (inject) hipLaunchKernelGGL((kf_lean<NSLOT, NZ, true, SIG, PPL>), dim3(grid), dim3(MCX_BLOCK), lds, s, a);
+    else hipLaunchKernelGGL((kf_lean<NSLOT, NZ, false, SIG, PPL>), dim3(grid), dim3(MCX_BLOCK), lds, s, a);
+    *grid_out = grid;
+}
+
+}  // namespace
+
+// host entry used by kf_fused.hip (fused_run_impl); returns the grid size (number of per-block partial records), or -1 when
+// the (slots, z) shape has no instantiation
+int mcx_launch_kf_lean(const FusedArgs& a, const mcx_sim_desc& sd, int n_cu, bool inject, hipStream_t s)
+{
+    int grid = -1;
+    switch (mcx_sim_signature(sd)) {
+    case SIG_VAS_CIR_E: launch_lean<2, 2, SIG_VAS_CIR_E>(a, n_cu, inject, s, &grid); break;
+#ifndef MCX_LEAN_ONE_SIG
+    case SIG_BS_A: launch_lean<1, 1, SIG_BS_A>(a, n_cu, inject, s, &grid); break;
+    case SIG_BS_E: launch_lean<1, 1, SIG_BS_E>(a, n_cu, inject, s, &grid); break;
+    case SIG_HESTON_QE: launch_lean<1, 2, SIG_HESTON_QE>(a, n_cu, inject, s, &grid); break;
+    case SIG_HESTON_E: launch_lean<1, 2, SIG_HESTON_E>(a, n_cu, inject, s, &grid); break;
+    case SIG_VAS_E: launch_lean<1, 1, SIG_VAS_E>(a, n_cu, inject, s, &grid); break;
+    case SIG_VAS_A: launch_lean<1, 1, SIG_VAS_A>(a, n_cu, inject, s, &grid); break;
+    case SIG_BS_VAS_CIRDET_E: launch_lean<3, 3, SIG_BS_VAS_CIRDET_E>(a, n_cu, inject, s, &grid); break;
+    default:
+        switch (sd.n_slots * 16 + sd.n_z) {
+        case 1 * 16 + 1: launch_lean<1, 1, SIG_GENERIC>(a, n_cu, inject, s, &grid); break;
+        case 1 * 16 + 2: launch_lean<1, 2, SIG_GENERIC>(a, n_cu, inject, s, &grid); break;
+        case 2 * 16 + 2: launch_lean<2, 2, SIG_GENERIC>(a, n_cu, inject, s, &grid); break;
+        case 3 * 16 + 3: launch_lean<3, 3, SIG_GENERIC>(a, n_cu, inject, s, &grid); break;
+        case 4 * 16 + 4: launch_lean<4, 4, SIG_GENERIC>(a, n_cu, inject, s, &grid); break;
+        default: break;
+        }
+#else
+    default: break;
+#endif
+    }
+    return grid;
+}

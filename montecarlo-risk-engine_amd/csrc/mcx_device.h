@@ -125,30 +125,30 @@ __device__ __forceinline__ double dev_barrier_event(const DevEvent& e, const Dev
 // TAB: `tab` is the block's LDS copy of the Box-Muller tables (mcx_bm_load); otherwise polynomial log / sincos
 template <bool TAB = false>
 __device__ __forceinline__ void draw_pair(uint64_t seed, uint64_t path, uint32_t step, uint32_t draw, double& ua, double& z0, double& z1,
-                                          const double* __restrict__ tab = nullptr)
+                                          const double* __restrict__ tab, const mcx_bm_coef& bc)
 {
     uint32_t w0, w1, w2, w3;
-#ifdef MCX_DBG_NOPHILOX     // timing experiment only: a cheap (non-random) stand-in for the counter-based generator
-    w0 = (uint32_t)path * 2654435761u + step; w1 = w0 ^ 0x9E3779B9u; w2 = w0 * 3u + draw; w3 = w1 + w2;
-#else
     philox4x32_10((uint32_t)path, (uint32_t)(path >> 32), step, draw, (uint32_t)seed, (uint32_t)(seed >> 32), w0, w1, w2, w3);
-#endif
     ua = u53(w0, w1);
     const double ub = u53(w2, w3);
-#ifdef MCX_DBG_NOBM          // timing experiment only
-    z0 = ua - 0.5; z1 = ub - 0.5;
-#else
     double s, c, r;
     if (TAB) {
-        r = mcx_sqrt(-2.0 * mcx_log_tab(ua, tab));
-        mcx_sincos2pi_tab(ub, tab, s, c);
+        r = mcx_sqrt(-2.0 * mcx_log_tab(ua, tab, bc));
+        mcx_sincos2pi_tab(ub, tab, s, c, bc);
     } else {
         r = mcx_sqrt(-2.0 * mcx_log(ua));
         mcx_sincos2pi(ub, s, c);
     }
     z0 = r * c;
     z1 = r * s;
-#endif
+}
+
+template <bool TAB = false>
+__device__ __forceinline__ void draw_pair(uint64_t seed, uint64_t path, uint32_t step, uint32_t draw, double& ua, double& z0, double& z1,
+                                          const double* __restrict__ tab = nullptr)
+{
+    const mcx_bm_coef bc = mcx_bm_coef_load();
+    draw_pair<TAB>(seed, path, step, draw, ua, z0, z1, tab, bc);
 }
 
 __device__ __forceinline__ double degree_of_truth(double x, bool fuzzy, double eps)
@@ -161,11 +161,13 @@ __device__ __forceinline__ double degree_of_truth(double x, bool fuzzy, double e
 // one sub-step of one sub-model (reference formulas, see oracle/mcx_oracle.c for the line-by-line citations)
 // KIND / SCHEME >= 0 are compile-time constants (specialised kernels: the switch folds away and only the parameters the
 // model really uses stay live in SGPRs); -1 = wave-uniform run-time dispatch (generic kernels).
-template <int KIND, int SCHEME>
-__device__ __forceinline__ void step_slot(const mcx_slot& sl, int scheme_rt, int flags, double dt, double sq,
+// SL / KA below: `mcx_slot` / `K1Args`, or their constant-address-space views (kf_lean.hip reads the kernel arguments through
+// a region-local pointer into the kernarg segment, so that every field is a scalar load at its point of use)
+template <int KIND, int SCHEME, class SL>
+__device__ __forceinline__ void step_slot(const SL& sl, int scheme_rt, int flags, double dt, double sq,
                                           const double* __restrict__ aux, double& s0, double& s1, double zc0, double zc1, double u)
 {
-    const double* p = sl.p;
+    const auto* p = sl.p;
     const int scheme = SCHEME >= 0 ? SCHEME : scheme_rt;
     switch (KIND >= 0 ? KIND : sl.kind) {
     case MCX_MODEL_BS:
@@ -191,7 +193,7 @@ __device__ __forceinline__ void step_slot(const mcx_slot& sl, int scheme_rt, int
     }
     case MCX_MODEL_CIRPP: {                                               // cirpp.py:188-198
         const double y = s0;
-        const double sy = mcx_sqrt(fmax(y, 0.0));
+        const double sy = mcx_sqrt(y);                    // = sqrt(clamp(y, 0)) of cirpp.py:194: mcx_sqrt returns 0 for y <= 0
         const double yn = y + p[0] * (p[1] - y) * dt + p[2] * sy * sq * zc0;
         s1 = s1 + (y + ldk(aux + 0)) * dt;
         s0 = fmax(yn, 1e-12);
@@ -277,8 +279,8 @@ static inline int mcx_sim_signature(const mcx_sim_desc& d)
 }
 
 // compile-time recursion over the slots (the slot index must be a constant expression for the signature lookup)
-template <int NSLOT, int NZ, int SIG, int S>
-__device__ __forceinline__ void step_slots(const K1Args& k, const mcx_step& sp, const double* __restrict__ ax,
+template <int NSLOT, int NZ, int SIG, int S, class KA>
+__device__ __forceinline__ void step_slots(const KA& k, const mcx_step& sp, const double* __restrict__ ax,
                                            double (&reg)[2 * NSLOT], const double (&zc)[NZ], double u)
 {
     if constexpr (S < NSLOT) {
@@ -292,9 +294,10 @@ __device__ __forceinline__ void step_slots(const K1Args& k, const mcx_step& sp, 
 }
 
 // one sub-step of the whole model for a lane: draws, Cholesky, per-slot maps.  reg[2s], reg[2s+1] = state of slot s.
-template <int NSLOT, int NZ, bool INJECT, int SIG>
-__device__ __forceinline__ void sim_substep(const K1Args& k, int step, uint64_t path, int64_t i, double (&reg)[2 * NSLOT],
-                                            const double* __restrict__ tab)
+// seed / bc: the Philox key and the Box-Muller coefficients (SGPRs) of the calling code region (mcx_math.h "region zero")
+template <int NSLOT, int NZ, bool INJECT, int SIG, class KA>
+__device__ __forceinline__ void sim_substep(const KA& k, int step, uint64_t path, int64_t i, double (&reg)[2 * NSLOT],
+                                            const double* __restrict__ tab, uint64_t seed, const mcx_bm_coef& bc)
 {
     const mcx_step sp = ldk_struct(&k.steps[step]);    // wave-uniform -> scalar loads
     double z[NZ], zc[NZ], u = 0.0;
@@ -307,13 +310,13 @@ __device__ __forceinline__ void sim_substep(const K1Args& k, int step, uint64_t 
 #pragma unroll
         for (int q = 0; q < (NZ + 1) / 2; ++q) {
             double z0, z1;
-            draw_pair<true>(k.seed, path, (uint32_t)step, (uint32_t)q, ua, z0, z1, tab);
+            draw_pair<true>(seed, path, (uint32_t)step, (uint32_t)q, ua, z0, z1, tab, bc);
             z[2 * q] = z0;
             if (2 * q + 1 < NZ) z[2 * q + 1] = z1;
         }
         if (sig_scheme(SIG) == MCX_SCHEME_QE || (sig_scheme(SIG) < 0 && k.n_uniform)) {
             double z0, z1;
-            draw_pair(k.seed, path, (uint32_t)step, (uint32_t)((NZ + 1) / 2), u, z0, z1);
+            draw_pair<false>(seed, path, (uint32_t)step, (uint32_t)((NZ + 1) / 2), u, z0, z1, nullptr, bc);
         }
     }
     const double* __restrict__ L = k.chol + (int64_t)sp.chol_idx * NZ * NZ;     // model.py:48  z @ chol.T
@@ -328,8 +331,16 @@ __device__ __forceinline__ void sim_substep(const K1Args& k, int step, uint64_t 
     step_slots<NSLOT, NZ, SIG, 0>(k, sp, ax, reg, zc, u);
 }
 
-template <int NSLOT, int SIG>
-__device__ __forceinline__ void sim_init_state(const K1Args& k, double (&reg)[2 * NSLOT])
+template <int NSLOT, int NZ, bool INJECT, int SIG>
+__device__ __forceinline__ void sim_substep(const K1Args& k, int step, uint64_t path, int64_t i, double (&reg)[2 * NSLOT],
+                                            const double* __restrict__ tab)
+{
+    const mcx_bm_coef bc = mcx_bm_coef_load();
+    sim_substep<NSLOT, NZ, INJECT, SIG>(k, step, path, i, reg, tab, k.seed, bc);
+}
+
+template <int NSLOT, int SIG, class KA>
+__device__ __forceinline__ void sim_init_state(const KA& k, double (&reg)[2 * NSLOT])
 {
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) {
@@ -339,8 +350,8 @@ __device__ __forceinline__ void sim_init_state(const K1Args& k, double (&reg)[2 
     }
 }
 
-template <int NSLOT, int SIG>
-__device__ __forceinline__ void sim_store_state(const K1Args& k, int t, int64_t i, const double (&reg)[2 * NSLOT])
+template <int NSLOT, int SIG, class KA>
+__device__ __forceinline__ void sim_store_state(const KA& k, int t, int64_t i, const double (&reg)[2 * NSLOT])
 {
     const int D = k.n_state;
 #pragma unroll

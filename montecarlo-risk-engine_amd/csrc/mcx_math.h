@@ -9,12 +9,46 @@
 #pragma once
 // (included from mcx_internal.h right after ldk())
 
-__device__ const double MCX_EXP_C[14] = {1.00000000000000000e+00, 1.00000000000000000e+00, 5.00000000000000000e-01, 1.66666666666666657e-01, 4.16666666666666644e-02, 8.33333333333333322e-03, 1.38888888888888894e-03, 1.98412698412698413e-04, 2.48015873015873016e-05, 2.75573192239858925e-06, 2.75573192239858883e-07, 2.50521083854417202e-08, 2.08767569878681002e-09, 1.60590438368216133e-10};
+__device__ const double MCX_EXP_C[14] __attribute__((aligned(64))) = {1.00000000000000000e+00, 1.00000000000000000e+00, 5.00000000000000000e-01, 1.66666666666666657e-01, 4.16666666666666644e-02, 8.33333333333333322e-03, 1.38888888888888894e-03, 1.98412698412698413e-04, 2.48015873015873016e-05, 2.75573192239858925e-06, 2.75573192239858883e-07, 2.50521083854417202e-08, 2.08767569878681002e-09, 1.60590438368216133e-10};
 __device__ const double MCX_SIN_C[10] = {3.14159265358979312e+00, -5.16771278004997026e+00, 2.55016403987734552e+00, -5.99264529320792105e-01, 8.21458866111282326e-02, -7.37043094571435044e-03, 4.66302805767612554e-04, -2.19153534478302173e-05, 7.95205400147551261e-07, -2.29484289972698730e-08};   // sin(pi r) = sum_k S_k r^(2k+1)
 __device__ const double MCX_COS_C[10] = {1.00000000000000000e+00, -4.93480220054467900e+00, 4.05871212641676848e+00, -1.33526276885458950e+00, 2.35330630358893206e-01, -2.58068913900140612e-02, 1.92957430940392314e-03, -1.04638104924845705e-04, 4.30306958703294729e-06, -1.38789524622137714e-07};   // cos(pi r) = sum_k C_k r^(2k)
 __device__ const double MCX_LOG_C[7] = {6.666666666666735130e-01, 3.999999999940941908e-01, 2.857142874366239149e-01, 2.222219843214978396e-01, 1.818357216161805012e-01, 1.531383769920937332e-01, 1.479819860511658591e-01};    // fdlibm e_log.c Lg1..Lg7
 
+// "Region zero": an SGPR that holds 0 but is opaque to the optimiser (volatile asm).  A coefficient-table read whose index
+// carries a region zero cannot be hoisted above the asm, so the table's SGPRs are live only inside the code region that
+// executed it (the date block, one run of the sub-step loop) instead of for the whole kernel: without it the backend keeps
+// ~60 loop-invariant coefficient SGPRs alive everywhere and spills them to VGPR lanes (v_writelane / v_readlane are VALU
+// instructions — the pipe these kernels are bound by).  Re-reading a table costs a couple of s_load_dwordx16 per region.
+__device__ __forceinline__ int mcx_region_zero()
+{
+    int z;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+    return z;
+}
+__device__ __forceinline__ uint32_t mcx_region_copy(uint32_t v)      // an SGPR copy the optimiser cannot trace back to v
+{
+    uint32_t o;
+    asm volatile("s_mov_b32 %0, %1" : "=s"(o) : "s"(v));
+    return o;
+}
+
 // exp(x), |x| <~ 708.  x = k ln2 + r, |r| <= ln2/2; Taylor degree 13 in r; scale by 2^k.
+struct mcx_exp_coef { double c[14]; };
+// the coefficient table as 28 SGPRs (two wide scalar loads); z: region zero (or literal 0)
+__device__ __forceinline__ mcx_exp_coef mcx_exp_load(int z = 0)
+{
+    return ldk_struct((const mcx_exp_coef*)(MCX_EXP_C + z));
+}
+__device__ __forceinline__ double mcx_exp(double x, const mcx_exp_coef& C)
+{
+    const double k = rint(x * 1.4426950408889634074);
+    double r = fma(k, -6.93147180369123816490e-01, x);       // ln2_hi
+    r = fma(k, -1.90821492927058770002e-10, r);              // ln2_lo
+    double p = C.c[13];
+#pragma unroll
+    for (int j = 12; j >= 0; --j) p = fma(p, r, C.c[j]);
+    return ldexp(p, (int)k);
+}
 __device__ __forceinline__ double mcx_exp(double x)
 {
     const double k = rint(x * 1.4426950408889634074);
@@ -70,19 +104,17 @@ __device__ __forceinline__ void mcx_sincos2pi(double u, double& s, double& c)
     c = ((q + 1) & 2) ? -b : b;
 }
 
-// sqrt(a) for a >= 0 in the normal range (Box-Muller radius^2, CIR state): v_rsq_f64 seed + Goldschmidt/Newton refinement
-// without the scaling / special-case code of the IEEE-complete library routine.  Correctly rounded in all but ~1e-3 of
-// cases (<= 1 ulp otherwise).
+// sqrt(a) for a >= 0 in the normal range (Box-Muller radius^2, CIR state): v_rsq_f64 seed (~2^-26) + one coupled
+// Goldschmidt step (~2^-50) + one residual correction, without the scaling / special-case code of the IEEE-complete library
+// routine.  <= 1 ulp (correctly rounded in ~99.9 % of cases; a second residual step changed no path beyond 1e-15).
 __device__ __forceinline__ double mcx_sqrt(double a)
 {
     const double y = __builtin_amdgcn_rsq(a);
     double g = a * y, h = 0.5 * y;
-    double r = fma(-h, g, 0.5);
+    const double r = fma(-h, g, 0.5);
     g = fma(g, r, g);
     h = fma(h, r, h);
-    double d = fma(-g, g, a);
-    g = fma(d, h, g);
-    d = fma(-g, g, a);
+    const double d = fma(-g, g, a);
     g = fma(d, h, g);
     return a > 0.0 ? g : 0.0;
 }
@@ -96,8 +128,14 @@ __device__ __forceinline__ double mcx_sqrt(double a)
 #include "mcx_tables.h"
 #define MCX_BM_LDS_DOUBLES 512
 
-__device__ const double MCX_LOG1P_C[6] = {-0.5, 1.0 / 3.0, -0.25, 0.2, -1.0 / 6.0, 1.0 / 7.0};
-__device__ const double MCX_TRIG_C[6] = {-1.0 / 6.0, 1.0 / 120.0, -1.0 / 5040.0, -0.5, 1.0 / 24.0, -1.0 / 720.0};
+// [0..5] log1p(t) = t + t^2 (c0 + c1 t + ...);  [6..8] sin d = d + d^3 (...);  [9..11] cos d = 1 + d^2 (...)
+__device__ const double MCX_BM_C[12] __attribute__((aligned(64))) = {-0.5, 1.0 / 3.0, -0.25, 0.2, -1.0 / 6.0, 1.0 / 7.0,
+                                                                     -1.0 / 6.0, 1.0 / 120.0, -1.0 / 5040.0, -0.5, 1.0 / 24.0, -1.0 / 720.0};
+struct mcx_bm_coef { double c[12]; };
+__device__ __forceinline__ mcx_bm_coef mcx_bm_coef_load(int z = 0)      // 24 SGPRs; z: region zero (or literal 0)
+{
+    return ldk_struct((const mcx_bm_coef*)(MCX_BM_C + z));
+}
 
 // cooperative copy of both tables into the block's LDS area (MCX_BM_LDS_DOUBLES doubles); includes the barrier
 __device__ __forceinline__ void mcx_bm_load(double* __restrict__ tab)
@@ -112,31 +150,31 @@ __device__ __forceinline__ void mcx_bm_load(double* __restrict__ tab)
 typedef double mcx_d2 __attribute__((ext_vector_type(2)));
 
 // log(x), x a normal double in (0, 1]
-__device__ __forceinline__ double mcx_log_tab(double x, const double* __restrict__ tab)
+__device__ __forceinline__ double mcx_log_tab(double x, const double* __restrict__ tab, const mcx_bm_coef& C)
 {
     const double m = __builtin_amdgcn_frexp_mant(x);                  // [0.5, 1)
     const int e = __builtin_amdgcn_frexp_exp(x);
     const int j = (__double2hiint(m) >> 13) & 127;                     // top 7 mantissa bits
     const mcx_d2 tc = ((const mcx_d2*)tab)[j];                        // (1/c, log c)
     const double t = fma(m, tc.x, -1.0);                               // |t| <= 2^-8
-    double q = ldk(MCX_LOG1P_C + 5);
+    double q = C.c[5];
 #pragma unroll
-    for (int k = 4; k >= 0; --k) q = fma(q, t, ldk(MCX_LOG1P_C + k));
+    for (int k = 4; k >= 0; --k) q = fma(q, t, C.c[k]);
     const double p = fma(t * t, q, t);                                 // log1p(t)
     const double dk = (double)e;
     return fma(dk, 6.93147180369123816490e-01, tc.y) + fma(dk, 1.90821492927058770002e-10, p);
 }
 
 // (sin, cos)(2 pi u), u in [0, 1]
-__device__ __forceinline__ void mcx_sincos2pi_tab(double u, const double* __restrict__ tab, double& s, double& c)
+__device__ __forceinline__ void mcx_sincos2pi_tab(double u, const double* __restrict__ tab, double& s, double& c, const mcx_bm_coef& C)
 {
     const double n = rint(u * 128.0);
     const double d = fma(n, -0.0078125, u) * 6.28318530717958647692;   // |d| <= pi/128
     const int j = (int)n & 127;
     const mcx_d2 sc = ((const mcx_d2*)(tab + 256))[j];
     const double d2 = d * d;
-    const double qs = fma(fma(ldk(MCX_TRIG_C + 2), d2, ldk(MCX_TRIG_C + 1)), d2, ldk(MCX_TRIG_C + 0));
-    const double qc = fma(fma(ldk(MCX_TRIG_C + 5), d2, ldk(MCX_TRIG_C + 4)), d2, ldk(MCX_TRIG_C + 3));
+    const double qs = fma(fma(C.c[8], d2, C.c[7]), d2, C.c[6]);
+    const double qc = fma(fma(C.c[11], d2, C.c[10]), d2, C.c[9]);
     const double ps = fma(d * d2, qs, d);                              // sin d
     const double pc = fma(d2, qc, 1.0);                                // cos d
     s = fma(sc.x, pc, sc.y * ps);

@@ -19,7 +19,7 @@ for f in glob.glob(f"{out}/sq_*/**/*counter_collection.csv", recursive=True):
         acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {}
 for k, d in acc.items():
-    if not any(s in k for s in ("k1_paths", "kf_fused")): continue
+    if not any(s in k for s in ("k1_paths", "kf_fused", "kf_lean")): continue
     row = {}
     for c, v in d.items():
         big = [x for x in v if x >= 0.5 * max(v)] if max(v) > 0 else v
@@ -29,7 +29,7 @@ json.dump(res, open(f"{out}/sq_summary.json", "w"), indent=1)
 # compact form read by bench.py (profiles/sq_counters.json)
 compact = {}
 for k, row in res.items():
-    short = "k1_paths" if "k1_paths" in k else "kf_fused"
+    short = "k1_paths" if "k1_paths" in k else "kf_lean" if "kf_lean" in k else "kf_fused"
     if "SQ_WAVES" in row and "SQ_INSTS_VALU" in row:
         w = row["SQ_WAVES"]
         compact[short] = {"kernel": k, "waves": w, "n_simd": 1024, "valu_insts_per_wave": row["SQ_INSTS_VALU"] / w,

@@ -26,7 +26,7 @@ for C in ("FETCH_SIZE", "WRITE_SIZE"):
         res[k][C] = {"launches": len(v), "avg_main_launch_KB": sum(big) / len(big)}
 summary = {}
 for k, v in res.items():
-    short = "k1_paths" if "k1_paths" in k else "kf_fused" if "kf_fused" in k else "k2_eval_book" if "k2_eval" in k else \
+    short = "k1_paths" if "k1_paths" in k else "kf_lean" if "kf_lean" in k else "kf_fused" if "kf_fused" in k else "k2_eval_book" if "k2_eval" in k else \
             "k4_cva_paths" if "k4_cva" in k else None
     if short:
         fetch = v.get("FETCH_SIZE", {}).get("avg_main_launch_KB", 0.0) * 1024 * 2      # gfx950 correction
