@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MCX_ABI_VERSION 2   /* 2: batched LSM, tangent-book kernels, bridge RNG, option aggregation modes, 8 exercise states */
+#define MCX_ABI_VERSION 3   /* 3: mcx_rng_draws, mcx_comm_* (RCCL), interpolated collateral; 2: batched LSM, tangent-book kernels, bridge RNG */
 
 #define MCX_MAX_SLOTS   8    /* sub-models in one ModelConfig                                  */
 #define MCX_MAX_Z       8    /* total simulation dimension (correlated normals per sub-step)    */
@@ -261,6 +261,12 @@ int  mcx_generate_paths(mcx_handle* h, const mcx_sim* sim, uint64_t seed, uint64
                         int64_t ld, double* d_paths /* [n_dates][n_state][ld] */,
                         const double* d_inject_z, const double* d_inject_u, void* stream);
 
+/* Probe of the RNG contract above (what the path kernels consume): for i < n the draw (path = path0 + i, step, draw) as
+ * d_words [4][n] Philox4x32-10 output words (bit-exact against Random123 / the oracle), d_u [2][n] = (ua, ub) and
+ * d_z [2][n] = the Box-Muller pair computed exactly as in the kernels (table-driven log / sincos).  Each output is nullable. */
+int  mcx_rng_draws(mcx_handle* h, uint64_t seed, uint64_t path0, int64_t n, uint32_t step, uint32_t draw,
+                   uint32_t* d_words, double* d_u, double* d_z, void* stream);
+
 /* K2 — replaces RequestInterface.resolve_requests + SimulationController._evaluate_product summed per netting set
  * (controller/controller.py:385-471, 584-591). d_cfs [n_netting_sets][ld_out], d_expo [n_netting_sets][n_expo_rows][ld_out]. */
 int  mcx_book_create(mcx_handle* h, const mcx_book_desc* desc, mcx_book** out);
@@ -416,6 +422,19 @@ int  mcx_unsecured(mcx_handle* h, const mcx_unsecured_desc* u, const double* d_e
 int  mcx_select_hist(mcx_handle* h, const mcx_unsecured_desc* u, const double* d_expo_ns, int64_t n_paths, int64_t ld,
                      int32_t n_sel, const uint64_t* h_prefix, int32_t shift, int32_t bits,
                      uint64_t* d_hist, void* stream);
+
+/* Multi-GPU exchange (paths shard over the GPUs of a node, one process per GPU; the only data that crosses
+ * GPUs are accumulator records, LSM moments and select histograms).  RCCL over xGMI, loaded at run time (librccl.so.1 — the
+ * library has no link-time dependency on it).  A caller without torch.distributed creates the id on rank 0
+ * (mcx_comm_unique_id), ships the 128 bytes to the other ranks by any means, and every rank calls mcx_comm_init.
+ * mcx_allreduce_f64 sums d_buf[0..n) in place over the ranks on `stream`; mcx_allgather_f64 gathers n doubles per rank into
+ * d_out [n_ranks][n].  One communicator per handle. */
+#define MCX_COMM_ID_BYTES 128
+int  mcx_comm_unique_id(mcx_handle* h, void* out_id /* MCX_COMM_ID_BYTES */);
+int  mcx_comm_init(mcx_handle* h, int32_t n_ranks, int32_t rank, const void* id /* MCX_COMM_ID_BYTES */);
+int  mcx_comm_destroy(mcx_handle* h);
+int  mcx_allreduce_f64(mcx_handle* h, double* d_buf, int64_t n, void* stream);
+int  mcx_allgather_f64(mcx_handle* h, const double* d_in, double* d_out, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

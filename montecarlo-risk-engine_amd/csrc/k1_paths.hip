@@ -66,7 +66,42 @@ int launch_k1(const K1Args& a, bool inject, hipStream_t s)
     return 0;
 }
 
+// the draw (path0 + i, step, draw) exactly as sim_substep consumes it: Philox words, the two uniforms, the Box-Muller pair
+__global__ __launch_bounds__(MCX_BLOCK) void k1_rng_draws(uint64_t seed, uint64_t path0, int64_t n, uint32_t step, uint32_t draw,
+                                                          uint32_t* __restrict__ words, double* __restrict__ u, double* __restrict__ z)
+{
+    __shared__ double bm_lds[MCX_BM_LDS_DOUBLES];
+    mcx_bm_load(bm_lds);
+    const mcx_bm_coef bc = mcx_bm_coef_load();
+    for (int64_t i = (int64_t)blockIdx.x * MCX_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * MCX_BLOCK) {
+        const uint64_t path = path0 + (uint64_t)i;
+        if (words) {
+            uint32_t w0, w1, w2, w3;
+            philox4x32_10((uint32_t)path, (uint32_t)(path >> 32), step, draw, (uint32_t)seed, (uint32_t)(seed >> 32), w0, w1, w2, w3);
+            words[i] = w0; words[n + i] = w1; words[2 * n + i] = w2; words[3 * n + i] = w3;
+            if (u) { u[i] = u53(w0, w1); u[n + i] = u53(w2, w3); }
+        }
+        if (z) {
+            double ua, z0, z1;
+            draw_pair<true>(seed, path, step, draw, ua, z0, z1, bm_lds, bc);
+            z[i] = z0; z[n + i] = z1;
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int mcx_rng_draws(mcx_handle* h, uint64_t seed, uint64_t path0, int64_t n, uint32_t step, uint32_t draw,
+                             uint32_t* d_words, double* d_u, double* d_z, void* stream)
+{
+    if (!h) return -1;
+    if (n <= 0) return 0;
+    if (d_u && !d_words) MCX_FAIL(h, -2, "mcx_rng_draws: d_u needs d_words");
+    const int grid = mcx_grid_for(n, MCX_BLOCK, 2048);
+    hipLaunchKernelGGL(k1_rng_draws, dim3(grid), dim3(MCX_BLOCK), 0, (hipStream_t)stream, seed, path0, n, step, draw, d_words, d_u, d_z);
+    MCX_HIP(h, hipGetLastError());
+    return 0;
+}
 
 extern "C" int mcx_sim_create(mcx_handle* h, const mcx_sim_desc* d, mcx_sim** out)
 {

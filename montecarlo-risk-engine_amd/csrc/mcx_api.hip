@@ -17,6 +17,7 @@ extern "C" int mcx_create(mcx_handle** out, int device_id)
     h->pinned_bytes = 1u << 20;
     h->d_ws = nullptr;
     h->h_pinned = nullptr;
+    h->comm = nullptr; h->comm_ranks = 1; h->comm_rank = 0;
     if (hipMalloc(&h->d_ws, h->ws_bytes) != hipSuccess) { delete h; return -5; }
     if (hipHostMalloc(&h->h_pinned, h->pinned_bytes, hipHostMallocDefault) != hipSuccess) { hipFree(h->d_ws); delete h; return -6; }
     *out = h;
@@ -26,6 +27,7 @@ extern "C" int mcx_create(mcx_handle** out, int device_id)
 extern "C" void mcx_destroy(mcx_handle* h)
 {
     if (!h) return;
+    mcx_comm_destroy(h);
     hipFree(h->d_ws);
     hipHostFree(h->h_pinned);
     delete h;

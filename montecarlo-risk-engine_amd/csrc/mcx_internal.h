@@ -25,6 +25,8 @@ struct mcx_handle {
     void* h_pinned;        // pinned staging for small device->host results
     size_t pinned_bytes;
     hipDeviceProp_t prop;
+    void* comm;            // ncclComm_t of mcx_comm_init (mcx_comm.hip) or nullptr
+    int comm_ranks, comm_rank;
 };
 
 #define MCX_FAIL(h, code, ...)                                   \

@@ -19,7 +19,8 @@ LIB_PATH = os.environ.get("MCX_LIB_PATH") or os.path.join(os.path.dirname(_HERE)
 
 _EXPORTS = [
     "mcx_abi_version", "mcx_create", "mcx_destroy", "mcx_last_error", "mcx_device_info",
-    "mcx_sim_create", "mcx_sim_destroy", "mcx_generate_paths",
+    "mcx_sim_create", "mcx_sim_destroy", "mcx_generate_paths", "mcx_rng_draws",
+    "mcx_comm_unique_id", "mcx_comm_init", "mcx_comm_destroy", "mcx_allreduce_f64", "mcx_allgather_f64",
     "mcx_book_create", "mcx_book_destroy", "mcx_book_set_coeffs", "mcx_eval_book", "mcx_resolve_atoms",
     "mcx_lsm_stats", "mcx_lsm_step", "mcx_lsm_step_batch", "mcx_book_set_coeffs_batch", "mcx_book_set_bridge_rng",
     "mcx_fused_is_straight_line", "mcx_tangent_paths", "mcx_tangent_lsm", "mcx_tangent_eval", "mcx_tangent_cva", "mcx_tangent_profiles", "mcx_tangent_pick",
@@ -128,6 +129,41 @@ class HipBackend:
             self.h, sim.ptr, C.c_uint64(seed), C.c_uint64(path_offset), C.c_int64(n_paths), C.c_int64(n_paths),
             _vp(out.data_ptr()), _vp(inject_z.data_ptr() if inject_z is not None else 0),
             _vp(inject_u.data_ptr() if inject_u is not None else 0), self._stream()), "mcx_generate_paths")
+        return out
+
+    def rng_draws(self, seed: int, path0: int, n: int, step: int, draw: int):
+        """the RNG contract as the kernels consume it: (words uint32 [4][n], uniforms [2][n], Box-Muller pair [2][n])"""
+        words = torch.empty((4, n), dtype=torch.int32, device=self.device)
+        u = self.empty(2, n)
+        z = self.empty(2, n)
+        self._check(self.lib.mcx_rng_draws(self.h, C.c_uint64(seed), C.c_uint64(path0), C.c_int64(n), C.c_uint32(step),
+                                           C.c_uint32(draw), _vp(words.data_ptr()), _vp(u.data_ptr()), _vp(z.data_ptr()),
+                                           self._stream()), "mcx_rng_draws")
+        return words, u, z
+
+    # ---- multi-GPU exchange through the C ABI (RCCL; mcx/parallel.py uses torch.distributed for the same collectives) ---
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        self._check(self.lib.mcx_comm_unique_id(self.h, buf), "mcx_comm_unique_id")
+        return buf.raw
+
+    def comm_init(self, n_ranks: int, rank: int, uid: bytes):
+        assert len(uid) == 128
+        self._check(self.lib.mcx_comm_init(self.h, C.c_int32(n_ranks), C.c_int32(rank), C.c_char_p(uid)), "mcx_comm_init")
+
+    def comm_destroy(self):
+        self._check(self.lib.mcx_comm_destroy(self.h), "mcx_comm_destroy")
+
+    def allreduce_(self, t: torch.Tensor) -> torch.Tensor:
+        assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()
+        self._check(self.lib.mcx_allreduce_f64(self.h, _vp(t.data_ptr()), C.c_int64(t.numel()), self._stream()), "mcx_allreduce_f64")
+        return t
+
+    def allgather(self, t: torch.Tensor, n_ranks: int) -> torch.Tensor:
+        assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()
+        out = torch.empty((n_ranks,) + tuple(t.shape), dtype=torch.float64, device=t.device)
+        self._check(self.lib.mcx_allgather_f64(self.h, _vp(t.data_ptr()), _vp(out.data_ptr()), C.c_int64(t.numel()), self._stream()),
+                    "mcx_allgather_f64")
         return out
 
     # ---- K2 ------------------------------------------------------------------------------------------------------

@@ -72,9 +72,9 @@ def test_philox_gpu_vs_oracle(name, fused, hip, oracle):
                 assert np.allclose(a[:, 1], b[:, 1], rtol=1e-5, atol=1e-11), (name, metric.get_name(), a[:, 1], b[:, 1])
 
 
-def test_philox_stream_bit_exact(hip, oracle):
-    """BS exact with sigma*sqrt(dt)=1, rate=0, one step: log(S) is the N(0,1) draw -> compares the whole RNG pipeline.
-    Integer Philox output is bit-exact by construction (same u53); the normals may differ by libm ulps."""
+def test_philox_paths_through_the_qe_scheme(hip, oracle):
+    """Heston QE paths on identical counters: the whole RNG pipeline (normals + the extra uniform) through a scheme; the
+    integer stream itself is compared word for word in test_philox_device_*; the normals may differ by libm ulps."""
     from mcx.common.enums import SimulationScheme
     from mcx.engine.engine import MonteCarloEngine
     from mcx.models.heston import HestonModel
@@ -86,6 +86,62 @@ def test_philox_stream_bit_exact(hip, oracle):
         eng = MonteCarloEngine(tl, SimulationScheme.QE, model, n, 3, backend=be, path_offset=123456789012)
         out[be.name] = eng.generate_paths_native().cpu().numpy()
     assert np.allclose(out["hip"], out["oracle"], rtol=1e-11, atol=1e-13)
+
+
+KATS = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),          # Random123 kat_vectors, philox4x32 10
+        ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+        ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+
+
+def test_philox_device_words_match_random123_kats(hip):
+    """the integer stream ON THE DEVICE, word for word (mcx_rng_draws; counter = (path_lo, path_hi, step, draw), key = seed)"""
+    for ctr, key, exp in KATS:
+        words, _, _ = hip.rng_draws(seed=key[0] | (key[1] << 32), path0=ctr[0] | (ctr[1] << 32), n=1, step=ctr[2], draw=ctr[3])
+        got = tuple(int(w) & 0xffffffff for w in words.cpu().numpy()[:, 0])
+        assert got == exp, (hex(got[0]), hex(exp[0]))
+
+
+def test_philox_device_stream_bit_exact_vs_oracle(hip, oracle):
+    """2^20 counters: device words == oracle words (array_equal), the 53-bit uniforms bit for bit, the table-driven Box-Muller
+    pair against the oracle's libm pair to 1e-14 absolute"""
+    import ctypes as C
+    n, seed, path0, step, draw = 1 << 20, 43, (1 << 33) + 12345, 17, 1
+    words, u, z = hip.rng_draws(seed, path0, n, step, draw)
+    words = words.cpu().numpy().view(np.uint32)
+    u, z = u.cpu().numpy(), z.cpu().numpy()
+    # oracle words for every counter (vectorised restatement of orc_philox4x32_10 checked against the C oracle on a sample)
+    path = np.uint64(path0) + np.arange(n, dtype=np.uint64)
+    c = [(path & np.uint64(0xffffffff)).astype(np.uint64), (path >> np.uint64(32)).astype(np.uint64),
+         np.full(n, step, np.uint64), np.full(n, draw, np.uint64)]
+    k0, k1 = np.uint64(seed & 0xffffffff), np.uint64(seed >> 32)
+    M0, M1, W0, W1, MASK = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0x9E3779B9), np.uint64(0xBB67AE85), np.uint64(0xffffffff)
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        c = [(p1 >> np.uint64(32)) ^ c[1] ^ k0, p1 & MASK, (p0 >> np.uint64(32)) ^ c[3] ^ k1, p0 & MASK]
+        k0, k1 = (k0 + W0) & MASK, (k1 + W1) & MASK
+    ref = np.stack(c).astype(np.uint32)
+    for i in (0, 1, 777, n - 1):                                   # the numpy restatement IS the C oracle
+        cc = (C.c_uint32 * 4)(int(path[i]) & 0xffffffff, int(path[i]) >> 32, step, draw)
+        kk = (C.c_uint32 * 2)(seed & 0xffffffff, seed >> 32)
+        oo = (C.c_uint32 * 4)()
+        oracle.lib.orc_philox4x32_10(cc, kk, oo)
+        assert tuple(oo) == tuple(int(x) for x in ref[:, i])
+    assert np.array_equal(words, ref)
+    x0 = (ref[1].astype(np.uint64) << np.uint64(32)) | ref[0].astype(np.uint64)
+    x1 = (ref[3].astype(np.uint64) << np.uint64(32)) | ref[2].astype(np.uint64)
+    u_ref = np.stack([((x0 >> np.uint64(11)).astype(np.float64) + 0.5) * 2.0 ** -53, ((x1 >> np.uint64(11)).astype(np.float64) + 0.5) * 2.0 ** -53])
+    assert np.array_equal(u.view(np.uint64), u_ref.view(np.uint64))
+    r = np.sqrt(-2.0 * np.log(u_ref[0]))
+    z_ref = np.stack([r * np.cos(2.0 * np.pi * u_ref[1]), r * np.sin(2.0 * np.pi * u_ref[1])])
+    assert np.abs(z - z_ref).max() < 1e-14 * max(1.0, np.abs(z_ref).max())
+
+
+def test_lsm_mfma_matches_golden_coefficients(hip):
+    """the MFMA Gram kernel against the reference's recorded regression coefficients (not only against the VALU kernel)"""
+    sc, g = cases.make_controller("bermudan_swaption", hip)
+    sc.use_mfma = True
+    res = sc.run_simulation()
+    _check_against_golden(sc, res, g, "bermudan_swaption[mfma]")
 
 
 def test_lsm_mfma_matches_valu(hip):
@@ -341,6 +397,22 @@ def test_rccl_collectives_single_rank_group(hip):
     sc2, _ = cases.make_controller("irs_cva", hip, inject=False)
     b = sc2.run_simulation().results[0][0][0]
     assert a[0] == b[0]
+
+
+def test_comm_entry_points_single_rank(hip):
+    """mcx_comm_* of the C ABI (RCCL loaded with dlopen): a one-rank communicator, all-reduce and all-gather of device buffers"""
+    uid = hip.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    hip.comm_init(1, 0, uid)
+    try:
+        t = torch.arange(1000, dtype=torch.float64, device=hip.device) * 0.5
+        ref = t.clone()
+        hip.allreduce_(t)
+        g = hip.allgather(ref, 1)
+        torch.cuda.synchronize()
+        assert torch.equal(t, ref) and g.shape == (1, 1000) and torch.equal(g[0], ref)
+    finally:
+        hip.comm_destroy()
 
 
 def test_forward_mode_collateralised_netting_set_matches_bumps(hip):
