@@ -1,18 +1,25 @@
 #!/usr/bin/env python3
-"""bench.py — headline metric of BASELINE.json: path-steps/sec at 1M paths x 250 steps (per GPU).
+"""bench.py — headline metric of BASELINE.json: path-steps/sec at 1M paths x 250 steps; PV/CVA rel-error vs CPU ref.
 
 Workload: correlated Vasicek + CIR++ (rho = 0.5) payer IRS CVA, 12.5y quarterly swap,
 51 exposure dates x 5 Euler sub-steps = 250 steps, 1,048,576 main-simulation paths PER GPU (weak scaling: paths are
-sharded, one process per GPU, the only exchange is the gather of the (n, shift, s1, s2) accumulator record).
-A "step" = one pass of the hot path over the batch: K1 path generation -> K2 book evaluation -> K4 CVA reduction
-(+ collective). The LSM pre-simulation (131,072 paths) runs once before the timed region and is reported separately.
+sharded, one process per GPU; the only exchange of a pass is ONE all-gather of the 32-byte accumulator records).
+A "step" = one pass of the hot path over the batch: Philox + Box-Muller + SDE sub-steps, cashflows / regression exposure,
+CVA reduction (+ the collective).  The LSM pre-simulation (131,072 paths per GPU) runs once before the timed region.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--paths P]
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--paths P] [--scaling weak|strong]
+
+--gpus N > 1 without a torch.distributed environment: this process starts N ranks itself
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>`) BEFORE
+touching the GPU and relays rank 0's JSON line; launched under torch.distributed.run (WORLD_SIZE set) it is one of the ranks.
 """
 import argparse
+import hashlib
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,17 +28,16 @@ for p in (os.path.join(ROOT, "montecarlo-risk-engine_amd"), os.path.join(ROOT, "
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 HAZARDS = {0.5: 0.006402303360855854, 1.0: 0.01553038972325307, 2.0: 0.009729741230773657, 3.0: 0.015552544648116201,
            4.0: 0.021196186202801115, 5.0: 0.02284319986706472, 7.0: 0.010111423894480876, 10.0: 0.00613267811172937,
            15.0: 0.0036969930706003337, 20.0: 0.003791311459217732}
-HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0                               # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+REF_CVA, REF_CVA_SE = 0.004623, 0.000012            # the reference itself on this workload at 50 k + 50 k paths
+KERNEL_SOURCES = ["kf_lean.hip", "kf_common.h", "mcx_device.h", "mcx_math.h"]      # what the dominant kernel is compiled from
 
 
 def build_controller(n_main, n_pre, backend):
+    import numpy as np
     from mcx.common.enums import SimulationScheme
     from mcx.controller.controller import SimulationController
     from mcx.metrics.cva_metric import CVAMetric
@@ -50,26 +56,54 @@ def build_controller(n_main, n_pre, backend):
     return SimulationController(ns, model, rm, n_main, n_pre, 5, SimulationScheme.EULER, backend=backend)
 
 
+def kernel_source_sha():
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, "montecarlo-risk-engine_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(target_seconds=12.0):
-    """the CPU oracle (oracle/mcx_oracle.c, OpenMP over paths) on a bounded sample of the same workload"""
+    """the CPU oracle (oracle/mcx_oracle.c, OpenMP over paths) on a bounded sample of the same workload; returns the baseline
+    object and (sample paths, pre-simulation paths, oracle CVA) for the GPU-vs-CPU comparison on identical Philox counters"""
     from oracle_backend import OracleBackend
     be = OracleBackend()
     threads = int(be.lib.orc_num_threads())
+    n_pre = 16384
 
     def run(n):
-        sc = build_controller(n, 16384, be)
+        sc = build_controller(n, n_pre, be)
         sc.prepare()
         t0 = time.perf_counter()
-        sc.main_pass()
-        return time.perf_counter() - t0, sc.sim_plan.n_steps
+        res = sc.main_pass()
+        return time.perf_counter() - t0, sc.sim_plan.n_steps, res[0][0][0]
 
-    t, S = run(16384)
+    t, S, _ = run(16384)
     rate = 16384 * S / t
     n = int(min(1 << 20, max(16384, rate * target_seconds / S)))
     n = (n // 4096) * 4096
-    t, S = run(n)
-    return {"value": n * S / t, "unit": "path-steps/s", "cores": threads, "kind": "port",
-            "sample": f"{n} paths x {S} steps of the same workload (K1+K2+K4 on the CPU oracle, OpenMP {threads} threads), {t:.2f} s"}
+    t, S, cva = run(n)
+    obj = {"value": n * S / t, "unit": "path-steps/s", "cores": threads, "kind": "port",
+           "sample": f"{n} paths x {S} steps of the same workload (path generation + book + CVA on the CPU oracle, OpenMP {threads} threads), {t:.2f} s"}
+    return obj, (n, n_pre, cva)
+
+
+def launch_ranks(args, argv):
+    """parent of an N-GPU run: never touches the GPU; starts the ranks, relays rank 0's JSON line, returns their exit code"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    if lines:
+        print(lines[-1], flush=True)
+    else:
+        sys.stderr.write(proc.stdout)
+    return proc.returncode if lines or proc.returncode else 1
 
 
 def main():
@@ -77,25 +111,37 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--paths", type=int, default=1 << 20, help="main-simulation paths PER GPU")
-    ap.add_argument("--presim", type=int, default=131072, help="pre-simulation (LSM) paths PER GPU")
+    ap.add_argument("--paths", type=int, default=1 << 20, help="main-simulation paths PER GPU (weak) / in total (strong)")
+    ap.add_argument("--presim", type=int, default=131072, help="pre-simulation (LSM) paths PER GPU (weak) / in total (strong)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--plan", default="auto", choices=["auto", "semi", "fused", "unfused"],
-                    help="main-pass execution plan: semi = K1 + one book/metric kernel; fused = one launch; unfused = K1,K2,K4")
+                    help="main-pass execution plan: fused = one launch; semi = K1 + one book/metric kernel; unfused = K1,K2,K4")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node == --gpus\n")
+        sys.exit(2)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    grouped = "WORLD_SIZE" in os.environ                # under torch.distributed.run (also with one rank): RCCL process group
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
 
     from mcx import _native
     be = _native.HipBackend(local_rank)
-    sc = build_controller(args.paths * world, args.presim * world, be)
+    per_gpu = args.paths if args.scaling == "weak" else args.paths // world
+    pre_gpu = args.presim if args.scaling == "weak" else max(args.presim // world, 4096)
+    sc = build_controller(per_gpu * world, pre_gpu * world, be)
     t0 = time.perf_counter()
     sc.prepare()
     be.synchronize()
@@ -103,28 +149,29 @@ def main():
     S = sc.sim_plan.n_steps
     n_local = sc._main_engine.num_paths
     T, D, E = sc.sim_plan.n_dates, sc.sim_plan.n_state, len(sc.exposure_timeline)
-    paths_buf = be.empty(T, D, n_local)
+    paths_buf = None
 
     def barrier():
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
-    res = None
-    # two execution plans exist for the main pass (one fused launch / K1+K2+K4 launches); time both once, keep the faster
-    plan_ms = {}
+    # three execution plans exist for the main pass; time each once (N = 1) and keep the fastest; N > 1 runs the one-launch plan
     fused_obj = sc._fused
-    names = ["semi", "fused", "unfused"]
-    if args.plan != "auto":
-        names = [args.plan]
+    names = ["fused", "semi", "unfused"] if args.plan == "auto" else [args.plan]
+    if world > 1 and args.plan == "auto":
+        names = ["fused"]
+    if fused_obj is None:
+        names = ["unfused"]
+    if any(n != "fused" for n in names):
+        paths_buf = be.empty(T, D, n_local)
 
     def set_plan(name):
         sc._fused = None if name == "unfused" else fused_obj
         sc.main_plan = name if name != "unfused" else sc.main_plan
 
+    plan_ms = {}
     for name in names:
-        if name != "unfused" and fused_obj is None:
-            continue
         set_plan(name)
         sc.main_pass(paths_buf if name != "fused" else None)
         barrier()
@@ -134,28 +181,25 @@ def main():
         barrier()
         plan_ms[name] = (time.perf_counter() - t0) / 2 * 1e3
     best = min(plan_ms, key=plan_ms.get)
-    if world > 1:      # all ranks must agree
-        flag = torch.tensor([float(names.index(best))], device="cuda")
-        dist.broadcast(flag, 0)
-        best = names[int(flag.item())]
     set_plan(best)
+    res = None
     for _ in range(args.warmup):
         res = sc.main_pass(paths_buf if best != "fused" else None)
-    # per-kernel device time of the dominant kernel (K1) with HIP events on the launch stream
+    # device time of the dominant kernel with HIP events on the launch stream (torch's current stream = the stream the
+    # library launches on, _native.HipBackend._stream)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    fused = best == "fused"
     barrier()
     t0 = time.perf_counter()
-    fused = best == "fused"
     for k in range(args.steps):
         ev[k][0].record()
         if fused:
-            res = sc._fused_pass()               # one launch: K1+K2+K4 (+ block merge, record copy, rank gather)
+            res = sc._fused_pass()               # one launch (+ block merge, record copy, rank gather)
             ev[k][1].record()
         elif best == "semi":
             paths = sc._main_engine.generate_paths_native(out=paths_buf)
             ev[k][1].record()                    # K1 device time; then ONE kernel for book + metrics
-            rec = be.fused_eval_paths(sc._fused, paths)
-            res = sc._finish_fused_records(rec)
+            res = sc._finish_fused_records(be.fused_eval_paths(sc._fused, paths))
         else:
             paths = sc._main_engine.generate_paths_native(out=paths_buf)
             ev[k][1].record()
@@ -163,7 +207,7 @@ def main():
             res = sc._evaluate_all(sc._shard, cfs, expo, paths)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if grouped:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -171,56 +215,77 @@ def main():
 
     if rank == 0:
         cva, err = res[0][0][0]
-        total_paths = n_local * world if world == 1 else args.paths * world
+        total_paths = n_local * world if world == 1 else per_gpu * world
         value = total_paths * S * args.steps / dt
         pass_bytes = 8.0 * (2 * T * D + 2 * E + 2) * n_local   # SURVEY.md §8d B_path for the whole pass
-        # HBM bytes per launch of the dominant kernel from the PMC counters (tools/measure_traffic.sh: separate FETCH_SIZE /
-        # WRITE_SIZE passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), measured at 2^20 paths
-        traffic = None
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            key = "kf_fused" if fused else "k1_paths"
-            if key in pm:
-                traffic = pm[key]["hbm_bytes_per_launch_at_1Mi_paths"] * (n_local / float(1 << 20))
-        except Exception:
-            traffic = None
-        # dominant kernel: the fused pass carries the whole pass's algorithmic bytes; unfused K1 only its output tensor
+        kname = ("kf_lean<2,2,SIG_VAS_CIR_E,PPL=2> (Philox + Box-Muller + SDE + LSM exposure + CVA in one launch)" if fused else
+                 "k1_paths<2,2,SIG_VAS_CIR_E> (Philox4x32-10 + Box-Muller + Cholesky + Vasicek/CIR++ Euler)")
         k1_bytes = pass_bytes if fused else 8.0 * T * D * n_local
         achieved = k1_bytes / (k1_ms * 1e-3) / 1e9
-        # the kernels are bound by f64 VALU issue, not HBM: companion figure from the SQ counters of
-        # tools/measure_sq.sh (VALU instructions per wave at 2^20 paths) and the live kernel time
-        alu = None
+        # counters of the dominant kernel (tools/measure_traffic.sh, tools/measure_sq.sh: separate rocprofv3 --pmc passes at
+        # 2^20 paths) — used only when they were taken from the kernel sources this library was built from
+        sha = kernel_source_sha()
+        traffic, alu, counters_note = None, None, None
         try:
-            sq = json.load(open(os.path.join(ROOT, "profiles", "sq_counters.json")))["kf_fused" if fused else "k1_paths"]
-            cycles = sq["valu_insts_per_wave"] * sq["waves"] * (n_local / float(1 << 20)) * 4.0 / sq["n_simd"]
-            alu = {"bound": "f64 VALU issue (4 clk per wave64 instruction)", "valu_insts_per_path_step": sq["valu_insts_per_wave"] * sq["waves"] * 64.0 / ((1 << 20) * S),
-                   "valu_busy_ms_at_2.4GHz": cycles / 2.4e6, "frac": cycles / 2.4e6 / k1_ms}
+            pm = json.load(open(os.path.join(ROOT, "profiles", "counters.json")))
+            if pm.get("kernel_source_sha") == sha:
+                c = pm["kf_lean" if fused else "k1_paths"]
+                traffic = c["hbm_bytes_per_launch_at_1Mi_paths"] * (n_local / float(1 << 20))
+                # VALU-issue model: wave-instructions per launch by class (SQ_INSTS_VALU total; the class mix of the sub-step loop
+                # from its ISA, tools/asm_mix.py; everything outside the sub-step loop is f64 polynomial work) x the SUSTAINED
+                # issue cost of the class measured by tools/ubench_valu on this chip, / 1024 SIMDs
+                per_ps = c["valu_insts_per_wave"] * c["waves"] * 64.0 / (float(1 << 20) * S)           # VALU per path and sub-step
+                mix = dict(pm["substep_mix_per_path"]) if fused else None
+                if mix:
+                    cls = {k: mix[k] for k in ("mad_u64_u32", "int32", "rsq_f64", "minmax_f64")}
+                    cls["f64"] = per_ps - sum(cls.values())
+                    ns = pm["issue_ns"]
+                    model_ms = sum(cls[k] * ns[k] for k in cls) * (n_local / 64.0) * S / 1024.0 * 1e-6
+                    alu = {"bound": "f64 VALU issue", "valu_insts_per_path_step": per_ps, "mix_per_path_step": cls,
+                           "issue_ns_per_wave_instruction_per_simd": ns, "modelled_ms": model_ms, "frac": model_ms / k1_ms,
+                           "note": "issue costs are the sustained rates tools/ubench_valu measures with every CU busy (under f64 VALU load "
+                                   "the clock settles near 1.7 GHz: v_fma_f64 = 2.36 ns per wave64 instruction per SIMD = 55 of the "
+                                   "78.6 TFLOP/s f64 spec); frac ~ 1 = the kernel runs at the rate the VALU pipe sustains",
+                           "source": "profiles/counters.json (tools/measure_counters.sh)"}
+            else:
+                counters_note = "profiles/counters.json was measured on other kernel sources: traffic / alu omitted"
         except Exception:
-            alu = None
+            counters_note = "profiles/counters.json missing: traffic / alu omitted"
         out = {
             "metric": "path-steps/sec at 1M paths x 250 steps; PV/CVA rel-error vs CPU ref",
             "value": value, "unit": "path-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "Vasicek+CIR++ (rho=0.5) payer IRS CVA, Euler, 51 dates x 5 sub-steps (SURVEY §8d config 3)",
                        "paths_per_gpu": n_local, "steps_per_path": S, "state_dim": D, "stored_dates": T,
-                       "exposure_dates": E, "presim_paths_per_gpu": args.presim, "parallelism": f"paths x{world}",
+                       "exposure_dates": E, "presim_paths_per_gpu": pre_gpu, "parallelism": f"paths x{world}",
                        "execution_plan": best, "plan_probe_ms": plan_ms},
-            "roofline": {"bound": "hbm", "kernel": "kf_fused_lean<2,2,SIG_VAS_CIR_E> (Philox + Box-Muller + SDE + cashflows + LSM exposure + CVA in one launch)" if fused else "k1_paths<2,2,SIG_VAS_CIR_E> (Philox4x32-10 + Box-Muller + Cholesky + Vasicek/CIR++ Euler)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel_ms": k1_ms, "algorithmic_bytes_per_launch": k1_bytes,
-                         "whole_pass_algorithmic_GBs": pass_bytes / (dt / args.steps) / 1e9},
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": k1_ms,
+                         "algorithmic_bytes_per_launch": k1_bytes,
+                         "note": "achieved = ALGORITHMIC bytes of the pass (SURVEY §8d: 4096 B/path, what the unfused dataflow "
+                                 "moves) / kernel time; the fused kernel materialises nothing (`traffic` = measured HBM bytes) and "
+                                 "is bound by f64 VALU issue: see `alu`"},
             "alu": alu,
-            "result": {"cva": cva, "mc_error": err},
+            "result": {"cva": cva, "mc_error": err, "z_vs_reference": (cva - REF_CVA) / math.hypot(err, REF_CVA_SE),
+                       "reference_cva": REF_CVA, "reference_mc_error": REF_CVA_SE},
             "prepare_s": t_prepare,
         }
+        if counters_note:
+            out["counters_note"] = counters_note
         if not args.no_cpu_baseline and world == 1:
-            cb = cpu_baseline()
+            cb, (n_s, n_pre_s, cva_cpu) = cpu_baseline()
             out["cpu_baseline"] = cb
-            # PV/CVA vs the CPU reference path: same Philox stream at the sample size -> direct comparison below
             out["gpu_over_cpu"] = value / cb["value"]
-        print(json.dumps(out))
-    if world > 1:
+            # PV/CVA vs the CPU reference path: the same sample on the GPU, identical Philox counters
+            sc_s = build_controller(n_s, n_pre_s, be)
+            sc_s.prepare()
+            cva_gpu_s, err_gpu_s = sc_s.main_pass()[0][0][0]
+            out["result"].update({"sample_paths": n_s, "cva_gpu_at_sample": cva_gpu_s, "cva_cpu_at_sample": cva_cpu[0],
+                                  "rel_error_vs_cpu": abs(cva_gpu_s - cva_cpu[0]) / abs(cva_cpu[0]),
+                                  "mc_error_rel_diff_vs_cpu": abs(err_gpu_s - cva_cpu[1]) / abs(cva_cpu[1])})
+        print(json.dumps(out), flush=True)
+    if grouped:
         dist.destroy_process_group()
 
 

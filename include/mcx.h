@@ -290,10 +290,20 @@ int  mcx_fused_run(mcx_handle* h, const mcx_fused* f, uint64_t seed, uint64_t pa
                    double* d_paths, int64_t ld, double* d_cfs, double* d_expo, int64_t ld_out,
                    const double* d_inject_z, const double* d_inject_u, mcx_acc* h_out, void* stream);
 
+/* the same pass with the records left in DEVICE memory (d_out [mcx_fused_num_records], caller-owned): stream-ordered, the call
+ * does not synchronise — for a multi-GPU caller that gathers the records of all ranks on the device (one RCCL all-gather,
+ * mcx_allgather_f64 or torch.distributed) before the single device-to-host copy of a pass */
+int  mcx_fused_run_device(mcx_handle* h, const mcx_fused* f, uint64_t seed, uint64_t path_offset, int64_t n_paths,
+                          double* d_paths, int64_t ld, double* d_cfs, double* d_expo, int64_t ld_out,
+                          const double* d_inject_z, const double* d_inject_u, mcx_acc* d_out, void* stream);
+
 /* same event/metric program on a paths tensor produced earlier by mcx_generate_paths: ONE pass over the paths replaces
  * mcx_eval_book + mcx_reduce_* (no exposure matrix is written unless d_expo is given). Record layout as mcx_fused_run. */
 int  mcx_fused_eval_paths(mcx_handle* h, const mcx_fused* f, const double* d_paths, int64_t n_paths, int64_t ld,
                           double* d_cfs, double* d_expo, int64_t ld_out, mcx_acc* h_out, void* stream);
+
+int  mcx_fused_eval_paths_device(mcx_handle* h, const mcx_fused* f, const double* d_paths, int64_t n_paths, int64_t ld,
+                                 double* d_cfs, double* d_expo, int64_t ld_out, mcx_acc* d_out, void* stream);
 
 /* Tangent (forward-mode) pass — replaces `torch.autograd.grad(value, model.get_model_params())` (controller.py:609-627) for
  * PV metrics of European options under a single Black-Scholes or Heston model (BASELINE configs 2 and 4): the path kernel

@@ -690,10 +690,15 @@ extern "C" int mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_boo
 
 static int fused_run_impl(mcx_handle* h, const mcx_fused* f, bool simulate, uint64_t seed, uint64_t path_offset, int64_t n_paths,
                           double* d_paths, int64_t ld, double* d_cfs, double* d_expo, int64_t ld_out,
-                          const double* d_inject_z, const double* d_inject_u, mcx_acc* h_out, void* stream)
+                          const double* d_inject_z, const double* d_inject_u, mcx_acc* h_out, mcx_acc* d_out, void* stream)
 {
-    if (!h || !f || !h_out) return -1;
-    if (n_paths <= 0) { memset(h_out, 0, sizeof(mcx_acc) * (size_t)f->n_rec); return 0; }
+    // exactly one of h_out (host records, the call synchronises) / d_out (device records, stream-ordered, no synchronisation)
+    if (!h || !f || (h_out == nullptr) == (d_out == nullptr)) return -1;
+    if (n_paths <= 0) {
+        if (h_out) memset(h_out, 0, sizeof(mcx_acc) * (size_t)f->n_rec);
+        else MCX_HIP(h, hipMemsetAsync(d_out, 0, sizeof(mcx_acc) * (size_t)f->n_rec, (hipStream_t)stream));
+        return 0;
+    }
     if ((d_paths || d_inject_z) && ld < n_paths) MCX_FAIL(h, -2, "mcx_fused_run: ld < n_paths");
     if ((d_cfs || d_expo) && ld_out < n_paths) MCX_FAIL(h, -2, "mcx_fused_run: ld_out < n_paths");
     if ((size_t)f->n_rec * sizeof(mcx_acc) > h->pinned_bytes) MCX_FAIL(h, -2, "mcx_fused_run: too many records");
@@ -743,8 +748,9 @@ static int fused_run_impl(mcx_handle* h, const mcx_fused* f, bool simulate, uint
         }
     }
     MCX_HIP(h, hipGetLastError());
-    hipLaunchKernelGGL(kf_merge, dim3(f->n_rec), dim3(MCX_BLOCK), 0, s, f->d_partials, f->n_rec, grid, f->d_out);
+    hipLaunchKernelGGL(kf_merge, dim3(f->n_rec), dim3(MCX_BLOCK), 0, s, f->d_partials, f->n_rec, grid, d_out ? d_out : f->d_out);
     MCX_HIP(h, hipGetLastError());
+    if (d_out) return 0;
     MCX_HIP(h, hipMemcpyAsync(h->h_pinned, f->d_out, sizeof(mcx_acc) * (size_t)f->n_rec, hipMemcpyDeviceToHost, s));
     MCX_HIP(h, hipStreamSynchronize(s));
     memcpy(h_out, h->h_pinned, sizeof(mcx_acc) * (size_t)f->n_rec);
@@ -760,11 +766,24 @@ extern "C" int mcx_fused_run(mcx_handle* h, const mcx_fused* f, uint64_t seed, u
                              double* d_paths, int64_t ld, double* d_cfs, double* d_expo, int64_t ld_out,
                              const double* d_inject_z, const double* d_inject_u, mcx_acc* h_out, void* stream)
 {
-    return fused_run_impl(h, f, true, seed, path_offset, n_paths, d_paths, ld, d_cfs, d_expo, ld_out, d_inject_z, d_inject_u, h_out, stream);
+    return fused_run_impl(h, f, true, seed, path_offset, n_paths, d_paths, ld, d_cfs, d_expo, ld_out, d_inject_z, d_inject_u, h_out, nullptr, stream);
+}
+
+extern "C" int mcx_fused_run_device(mcx_handle* h, const mcx_fused* f, uint64_t seed, uint64_t path_offset, int64_t n_paths,
+                                    double* d_paths, int64_t ld, double* d_cfs, double* d_expo, int64_t ld_out,
+                                    const double* d_inject_z, const double* d_inject_u, mcx_acc* d_out, void* stream)
+{
+    return fused_run_impl(h, f, true, seed, path_offset, n_paths, d_paths, ld, d_cfs, d_expo, ld_out, d_inject_z, d_inject_u, nullptr, d_out, stream);
 }
 
 extern "C" int mcx_fused_eval_paths(mcx_handle* h, const mcx_fused* f, const double* d_paths, int64_t n_paths, int64_t ld,
                                     double* d_cfs, double* d_expo, int64_t ld_out, mcx_acc* h_out, void* stream)
 {
-    return fused_run_impl(h, f, false, 0, 0, n_paths, const_cast<double*>(d_paths), ld, d_cfs, d_expo, ld_out, nullptr, nullptr, h_out, stream);
+    return fused_run_impl(h, f, false, 0, 0, n_paths, const_cast<double*>(d_paths), ld, d_cfs, d_expo, ld_out, nullptr, nullptr, h_out, nullptr, stream);
+}
+
+extern "C" int mcx_fused_eval_paths_device(mcx_handle* h, const mcx_fused* f, const double* d_paths, int64_t n_paths, int64_t ld,
+                                           double* d_cfs, double* d_expo, int64_t ld_out, mcx_acc* d_out, void* stream)
+{
+    return fused_run_impl(h, f, false, 0, 0, n_paths, const_cast<double*>(d_paths), ld, d_cfs, d_expo, ld_out, nullptr, nullptr, nullptr, d_out, stream);
 }

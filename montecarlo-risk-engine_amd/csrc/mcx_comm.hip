@@ -99,7 +99,7 @@ extern "C" int mcx_allreduce_f64(mcx_handle* h, double* d_buf, int64_t n, void* 
 {
     if (!h || !d_buf || n < 0) return -1;
     if (!h->comm) MCX_FAIL(h, -3, "mcx_allreduce_f64: call mcx_comm_init first");
-    if (n == 0 || h->comm_ranks == 1) return 0;
+    if (n == 0) return 0;
     RcclApi* api = rccl(h);
     if (!api) return -2;
     MCX_RCCL(h, api, api->AllReduce(d_buf, d_buf, (size_t)n, RCCL_FLOAT64, RCCL_SUM, (rccl_comm)h->comm, (hipStream_t)stream));

@@ -24,7 +24,7 @@ _EXPORTS = [
     "mcx_book_create", "mcx_book_destroy", "mcx_book_set_coeffs", "mcx_eval_book", "mcx_resolve_atoms",
     "mcx_lsm_stats", "mcx_lsm_step", "mcx_lsm_step_batch", "mcx_book_set_coeffs_batch", "mcx_book_set_bridge_rng",
     "mcx_fused_is_straight_line", "mcx_tangent_paths", "mcx_tangent_lsm", "mcx_tangent_eval", "mcx_tangent_cva", "mcx_tangent_profiles", "mcx_tangent_pick",
-    "mcx_tangent_european", "mcx_fused_create", "mcx_fused_destroy", "mcx_fused_num_records", "mcx_fused_run", "mcx_fused_eval_paths",
+    "mcx_tangent_european", "mcx_fused_create", "mcx_fused_destroy", "mcx_fused_num_records", "mcx_fused_run", "mcx_fused_eval_paths", "mcx_fused_run_device", "mcx_fused_eval_paths_device",
     "mcx_reduce_vector", "mcx_reduce_profiles", "mcx_reduce_cva", "mcx_unsecured", "mcx_select_hist",
 ]
 
@@ -226,9 +226,17 @@ class HipBackend:
         return f
 
     def fused_run(self, fused, seed: int, path_offset: int, n_paths: int, paths=None, cfs=None, expo=None,
-                  inject_z=None, inject_u=None) -> np.ndarray:
-        out = np.zeros(fused.plan.n_records, dtype=_abi.ACC_DTYPE)
+                  inject_z=None, inject_u=None, device_records: bool = False):
+        """records as a host structured array, or (device_records) as a device tensor [n_records][4] without synchronising"""
         dp = lambda t: _vp(t.data_ptr() if t is not None else 0)
+        if device_records:
+            rec = self.empty(fused.plan.n_records, 4)
+            self._check(self.lib.mcx_fused_run_device(
+                self.h, fused.ptr, C.c_uint64(seed), C.c_uint64(path_offset), C.c_int64(n_paths), dp(paths), C.c_int64(n_paths),
+                dp(cfs), dp(expo), C.c_int64(n_paths), dp(inject_z), dp(inject_u), _vp(rec.data_ptr()), self._stream()),
+                "mcx_fused_run_device")
+            return rec
+        out = np.zeros(fused.plan.n_records, dtype=_abi.ACC_DTYPE)
         self._check(self.lib.mcx_fused_run(
             self.h, fused.ptr, C.c_uint64(seed), C.c_uint64(path_offset), C.c_int64(n_paths), dp(paths), C.c_int64(n_paths),
             dp(cfs), dp(expo), C.c_int64(n_paths), dp(inject_z), dp(inject_u), _abi.ptr(out), self._stream()), "mcx_fused_run")
@@ -237,10 +245,15 @@ class HipBackend:
     def fused_is_straight_line(self, f) -> bool:
         return bool(self.lib.mcx_fused_is_straight_line(f.ptr))
 
-    def fused_eval_paths(self, fused, paths: torch.Tensor, cfs=None, expo=None) -> np.ndarray:
-        out = np.zeros(fused.plan.n_records, dtype=_abi.ACC_DTYPE)
+    def fused_eval_paths(self, fused, paths: torch.Tensor, cfs=None, expo=None, device_records: bool = False):
         n = paths.shape[2]
         dp = lambda t: _vp(t.data_ptr() if t is not None else 0)
+        if device_records:
+            rec = self.empty(fused.plan.n_records, 4)
+            self._check(self.lib.mcx_fused_eval_paths_device(self.h, fused.ptr, dp(paths), C.c_int64(n), C.c_int64(n), dp(cfs), dp(expo),
+                                                             C.c_int64(n), _vp(rec.data_ptr()), self._stream()), "mcx_fused_eval_paths_device")
+            return rec
+        out = np.zeros(fused.plan.n_records, dtype=_abi.ACC_DTYPE)
         self._check(self.lib.mcx_fused_eval_paths(self.h, fused.ptr, dp(paths), C.c_int64(n), C.c_int64(n), dp(cfs), dp(expo),
                                                   C.c_int64(n), _abi.ptr(out), self._stream()), "mcx_fused_eval_paths")
         return out

@@ -686,18 +686,23 @@ class SimulationController:
         bp = self.book_plan
         expo = be.empty(bp.n_netting_sets, bp.n_expo_rows, n) if (need_expo and bp.desc.want_expo) else None
         cfs = be.empty(bp.n_netting_sets, n) if (self.materialize and bp.desc.want_cfs) else None
+        # several GPUs: the records stay on the device until the ranks' records are gathered (one collective, one copy)
+        kw = dict(device_records=True) if self._shard.device_collectives else {}
         if semi:
             eng.generate_paths_native(out=paths)
-            rec = be.fused_eval_paths(f, paths, cfs=cfs, expo=expo)
+            rec = be.fused_eval_paths(f, paths, cfs=cfs, expo=expo, **kw)
         else:
             rec = be.fused_run(f, eng.seed, eng.path_offset, n, paths=paths, cfs=cfs, expo=expo,
-                               inject_z=eng.inject_z, inject_u=eng.inject_u)
+                               inject_z=eng.inject_z, inject_u=eng.inject_u, **kw)
         self.last_state.update(paths=paths, cfs=cfs, expo=expo)
         return self._finish_fused_records(rec, cfs, expo, paths)
 
     def _finish_fused_records(self, rec, cfs=None, expo=None, paths=None):
         f = self._fused
-        g = self._shard.all_gather_np(rec.view(np.float64).reshape(-1, 4))        # [world][n_rec][4]
+        if isinstance(rec, torch.Tensor):
+            g = self._shard.all_gather_dev(rec).cpu().numpy()                     # [world][n_rec][4]
+        else:
+            g = self._shard.all_gather_np(rec.view(np.float64).reshape(-1, 4))
         fused_records = []
         for ns_i, lay in enumerate(f.plan.layout):
             nd = lay["n_dates"]

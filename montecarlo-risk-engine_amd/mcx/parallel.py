@@ -49,6 +49,19 @@ class Shard:
         dist.all_reduce(t, group=self.group)
         return t.cpu().numpy()
 
+    @property
+    def device_collectives(self) -> bool:
+        """True when the process group moves device memory (RCCL): accumulator records then stay on the GPU until gathered
+        (also for a one-rank group, so that a single GPU exercises the same code path as eight)"""
+        return self.active and self.backend == "nccl"
+
+    def all_gather_dev(self, t: torch.Tensor) -> torch.Tensor:
+        """[world, *t.shape] on the device of t: ONE collective over xGMI, no host hop (the caller copies the result to the
+        host once per pass)"""
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
+        return out
+
     def all_gather_np(self, a: np.ndarray) -> np.ndarray:
         """stack equal-shaped float64 arrays of all ranks along a new leading axis (the single small collective that
         carries the (n, shift, s1, s2) accumulator records of every metric)"""
@@ -56,13 +69,8 @@ class Shard:
         if not self.active or self.world == 1:
             return a[None]
         t = torch.from_numpy(a).to(self._comm_device())
-        if self.backend == "nccl" and not getattr(self, "_no_tensor_gather", False):
-            try:                                                        # one collective, one device-to-host copy
-                out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-                dist.all_gather_into_tensor(out, t, group=self.group)
-                return out.cpu().numpy()
-            except (RuntimeError, NotImplementedError):                 # deterministic on every rank: all fall back together
-                self._no_tensor_gather = True
+        if self.backend == "nccl":
+            return self.all_gather_dev(t).cpu().numpy()
         out = [torch.empty_like(t) for _ in range(self.world)]
         dist.all_gather(out, t, group=self.group)
-        return np.stack([o.cpu().numpy() for o in out], axis=0)
+        return np.stack([o.numpy() for o in out], axis=0)

@@ -41,14 +41,21 @@ template <int OP> void run(const char* name, int ninstr_per_chain)
 {
     double* out; uint64_t* cyc; const int blocks = 256 * 8;   // 8 blocks of 4 waves per CU = 8 waves per SIMD
     hipMalloc(&out, blocks * 256 * 8); hipMalloc(&cyc, blocks * 8);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipLaunchKernelGGL(bench<OP>, dim3(blocks), dim3(256), 0, 0, out, cyc, 1.5);
-    hipLaunchKernelGGL(bench<OP>, dim3(blocks), dim3(256), 0, 0, out, cyc, 1.5);
+    hipEventRecord(e0, 0);
+    for (int r = 0; r < 20; ++r) hipLaunchKernelGGL(bench<OP>, dim3(blocks), dim3(256), 0, 0, out, cyc, 1.5);
+    hipEventRecord(e1, 0);
     hipDeviceSynchronize();
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
     uint64_t* h = new uint64_t[blocks]; hipMemcpy(h, cyc, blocks * 8, hipMemcpyDeviceToHost);
     double avg = 0; for (int b = 0; b < blocks; ++b) avg += h[b]; avg /= blocks;
     // each wave issues ITER*NCH*ninstr instr; 8 waves share a SIMD -> cycles per wave-instruction at full occupancy:
     double per = avg / (ITER * NCH * ninstr_per_chain) / 8.0;
-    printf("%-28s %8.0f ticks/wave-loop  => %.2f s_memtime-ticks per wave-instr per SIMD (8 waves resident)\n", name, avg, per);
+    // wall clock: 20 launches, each SIMD issues 8 waves x ITER*NCH*ninstr wave-instructions (+ ~5 % prologue/epilogue)
+    double ns_per = ms * 1e6 / 20.0 / (8.0 * ITER * NCH * ninstr_per_chain);
+    printf("%-28s %8.0f ticks/wave-loop  => %.2f s_memtime-ticks, %.3f ns wall per wave-instr per SIMD (8 waves resident) = %.2f clk at 2.4 GHz\n",
+           name, avg, per, ns_per, ns_per * 2.4);
     hipFree(out); hipFree(cyc); delete[] h;
 }
 int main()
