@@ -57,7 +57,9 @@ enum {
     MCX_MODEL_VASICEK   = 3, /* p = [r0, sigma, theta, a]                     state [r, logB]  vasicek.py:61-112           */
     MCX_MODEL_CIRPP     = 4, /* p = [kappa, theta, sigma, y0]                 state [y, Lambda] cirpp.py:174-198           */
     MCX_MODEL_CIRPP_DET = 5, /* deterministic hazard                          state [lam, Lambda] cirpp.py:155-172         */
-    MCX_MODEL_HW        = 6  /* Hull-White 1F: p = [r0, sigma, -, a], theta(t) in aux   hull_white.py:58-88 (spec only)    */
+    MCX_MODEL_HW        = 6, /* Hull-White 1F: p = [r0, sigma, -, a], theta(t) in aux   hull_white.py:58-88 (spec only)    */
+    MCX_MODEL_S2F       = 7  /* Schwartz two-factor: p = [rate, kappa, sigma_s, mu, sigma_l, rho, log F0(t0)]
+                                state [logS, x, y] (3 columns), 2 normals              schwartz_two_factor.py:147-196     */
 };
 
 /* per-(sub-step, slot) aux[] semantics (filled by the host from the model parameters and dt):
@@ -66,6 +68,7 @@ enum {
  *   HW        ANALYTICAL: aux0 = exp(-a*dt), aux1 = mean shift alpha(t2)-alpha(t1)*exp(-a dt); EULER: aux0 = theta(t1)
  *   CIRPP     EULER:      aux0 = psi(t1)
  *   CIRPP_DET any:        aux0 = lambda_mkt(t1), aux1 = lambda_mkt(t2)
+ *   S2F       ANALYTICAL: aux0 = exp(-kappa dt) (1 when kappa ~ 0), aux1 = log F0(t2)        EULER: aux1 = log F0(t2)
  *   HESTON    QE:         aux0 = E = exp(-kappa dt), aux1..aux5 = K0..K4, aux6 = sigma^2 E (1-E)/kappa, aux7 = theta sigma^2 (1-E)^2/(2 kappa)
  */
 
@@ -260,6 +263,14 @@ void mcx_sim_destroy(mcx_sim* sim);
 int  mcx_generate_paths(mcx_handle* h, const mcx_sim* sim, uint64_t seed, uint64_t path_offset, int64_t n_paths,
                         int64_t ld, double* d_paths /* [n_dates][n_state][ld] */,
                         const double* d_inject_z, const double* d_inject_u, void* stream);
+
+/* The same time loop started from a PER-PATH state d_init_state [n_state][ld] instead of the descriptor's initial state — the
+ * reference's Model.simulate_time_step_{analytically,euler,qe}(time1, time2, state, corr_randn) (models/vasicek.py:61-112,
+ * cirpp.py:174-198, ...) is this call on a one-step descriptor whose Cholesky factor is the identity, with the caller's
+ * correlated normals injected; also the restart of a simulation from stored states (nested simulation). */
+int  mcx_generate_paths_from_state(mcx_handle* h, const mcx_sim* sim, uint64_t seed, uint64_t path_offset, int64_t n_paths,
+                                   int64_t ld, const double* d_init_state, double* d_paths,
+                                   const double* d_inject_z, const double* d_inject_u, void* stream);
 
 /* Probe of the RNG contract above (what the path kernels consume): for i < n the draw (path = path0 + i, step, draw) as
  * d_words [4][n] Philox4x32-10 output words (bit-exact against Random123 / the oracle), d_u [2][n] = (ua, ub) and

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(MCX_BLOCK) void k1_paths(const K1Args a)
         idx[q] = tid + q * half;
         live[q] = idx[q] < a.n;
         if (!live[q]) idx[q] = a.n - 1;
-        sim_init_state<NSLOT, SIG>(a, reg[q]);
+        sim_init_state<NSLOT, SIG>(a, reg[q], idx[q]);
     }
     for (int t = 0; t < a.n_initial_store; ++t)
 #pragma unroll
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(MCX_BLOCK) void k1_paths(const K1Args a)
         const int st = ldk(&a.steps[k].store_idx);
         if (st >= 0)
 #pragma unroll
-            for (int q = 0; q < PPL; ++q) if (live[q]) sim_store_state<NSLOT, SIG>(a, st, idx[q], reg[q]);
+            for (int q = 0; q < PPL; ++q) if (live[q]) sim_store_state<NSLOT, SIG>(a, st, idx[q], reg[q], a.aux + (int64_t)k * NSLOT * MCX_AUX);
     }
 }
 
@@ -112,7 +112,8 @@ extern "C" int mcx_sim_create(mcx_handle* h, const mcx_sim_desc* d, mcx_sim** ou
         MCX_FAIL(h, -3, "mcx_sim_create: a multi-model configuration needs simulation_dim == 1 per sub-model");
     int so = 0;
     for (int s = 0; s < d->n_slots; ++s) {
-        const int sd = d->slots[s].kind == MCX_MODEL_BS ? 1 : 2;
+        const int sd = mcx_kind_state_dim(d->slots[s].kind);
+        if (d->slots[s].kind == MCX_MODEL_S2F && d->n_slots != 1) MCX_FAIL(h, -3, "mcx_sim_create: the Schwartz two-factor model runs alone");
         if (d->slots[s].state_off != so) MCX_FAIL(h, -4, "mcx_sim_create: state offsets must be packed");
         so += sd;
     }
@@ -155,8 +156,25 @@ extern "C" void mcx_sim_destroy(mcx_sim* sim)
     delete sim;
 }
 
+static int generate_paths_impl(mcx_handle* h, const mcx_sim* sim, uint64_t seed, uint64_t path_offset, int64_t n_paths, int64_t ld,
+                               const double* d_init_state, double* d_paths, const double* d_inject_z, const double* d_inject_u, void* stream);
+
 extern "C" int mcx_generate_paths(mcx_handle* h, const mcx_sim* sim, uint64_t seed, uint64_t path_offset, int64_t n_paths,
                                   int64_t ld, double* d_paths, const double* d_inject_z, const double* d_inject_u, void* stream)
+{
+    return generate_paths_impl(h, sim, seed, path_offset, n_paths, ld, nullptr, d_paths, d_inject_z, d_inject_u, stream);
+}
+
+extern "C" int mcx_generate_paths_from_state(mcx_handle* h, const mcx_sim* sim, uint64_t seed, uint64_t path_offset, int64_t n_paths,
+                                             int64_t ld, const double* d_init_state, double* d_paths,
+                                             const double* d_inject_z, const double* d_inject_u, void* stream)
+{
+    if (!d_init_state) return -1;
+    return generate_paths_impl(h, sim, seed, path_offset, n_paths, ld, d_init_state, d_paths, d_inject_z, d_inject_u, stream);
+}
+
+static int generate_paths_impl(mcx_handle* h, const mcx_sim* sim, uint64_t seed, uint64_t path_offset, int64_t n_paths, int64_t ld,
+                               const double* d_init_state, double* d_paths, const double* d_inject_z, const double* d_inject_u, void* stream)
 {
     if (!h || !sim || !d_paths) return -1;
     if (n_paths <= 0) return 0;
@@ -165,6 +183,7 @@ extern "C" int mcx_generate_paths(mcx_handle* h, const mcx_sim* sim, uint64_t se
     if (d.n_uniform && d_inject_z && !d_inject_u) MCX_FAIL(h, -3, "mcx_generate_paths: inject_u required with inject_z under QE");
     K1Args a;
     mcx_fill_k1_args(sim, seed, path_offset, n_paths, ld, d_paths, d_inject_z, d_inject_u, &a);
+    a.init_paths = d_init_state;
     hipStream_t s = (hipStream_t)stream;
     const bool inj = d_inject_z != nullptr;
     switch (mcx_sim_signature(d)) {       // specialised (compile-time model kinds) instantiations of the hot configurations

@@ -452,6 +452,8 @@ extern "C" int mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_boo
         MCX_FAIL(h, MCX_E_NOT_FUSABLE, "not fusable: %d netting sets (max %d)", book->n_netting_sets, MCX_FUSED_MAX_NS);
     if (d->n_expo_rows != book->n_expo_rows) MCX_FAIL(h, -2, "mcx_fused_create: n_expo_rows mismatch");
     const int T = sd.n_dates;
+    for (int s = 0; s < sd.n_slots; ++s)
+        if (sd.slots[s].kind == MCX_MODEL_S2F) MCX_FAIL(h, MCX_E_NOT_FUSABLE, "not fusable: the Schwartz two-factor spot is a derived state column");
     // state column -> lane register
     int col_reg[MCX_MAX_STATE];
     for (int s = 0; s < sd.n_slots; ++s) {

@@ -12,6 +12,7 @@ struct K1Args {
     double* __restrict__ paths;
     const double* __restrict__ inject_z;
     const double* __restrict__ inject_u;
+    const double* __restrict__ init_paths;     // nullable: per-path initial state [n_state][ld] (mcx_generate_paths_from_state)
     int64_t n, ld;
     uint64_t seed, path_offset;
     int32_t scheme, n_steps, n_state, n_initial_store, flags, n_uniform;
@@ -203,6 +204,17 @@ __device__ __forceinline__ void step_slot(const SL& sl, int scheme_rt, int flags
         s1 = s1 + ldk(aux + 0) * dt;
         s0 = ldk(aux + 1);
         break;
+    case MCX_MODEL_S2F: {                                                 // schwartz_two_factor.py:147-196; registers (x, y)
+        const double x = s0, y = s1;
+        if (scheme == MCX_SCHEME_ANALYTICAL) {
+            s0 = x * ldk(aux + 0) + zc0;                                  // short factor: mean reversion + w_x
+            s1 = y + p[3] * dt + zc1;                                     // long factor: drift + w_y
+        } else {
+            s0 = x - p[1] * x * dt + p[2] * sq * zc0;
+            s1 = y + p[3] * dt + p[4] * sq * zc1;
+        }
+        break;
+    }
     case MCX_MODEL_HESTON: {
         const double logS = s0, v = s1;
         const double sigma = p[1], rate = p[2], kappa = p[4], theta = p[5];
@@ -339,26 +351,49 @@ __device__ __forceinline__ void sim_substep(const K1Args& k, int step, uint64_t 
     sim_substep<NSLOT, NZ, INJECT, SIG>(k, step, path, i, reg, tab, k.seed, bc);
 }
 
+// state columns of a slot kind: Black-Scholes 1, Schwartz two-factor 3 (log S is derived: log F0(t) + x + y), the others 2
+__host__ __device__ constexpr int mcx_kind_state_dim(int kind) { return kind == MCX_MODEL_BS ? 1 : kind == MCX_MODEL_S2F ? 3 : 2; }
+
+// i: the lane's path (used only when the run starts from a per-path state tensor)
 template <int NSLOT, int SIG, class KA>
-__device__ __forceinline__ void sim_init_state(const KA& k, double (&reg)[2 * NSLOT])
+__device__ __forceinline__ void sim_init_state(const KA& k, double (&reg)[2 * NSLOT], int64_t i = 0)
 {
+    const double* __restrict__ ip = k.init_paths;
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) {
-        const bool bs = sig_kind(SIG, s) >= 0 ? sig_is_bs(SIG, s) : (k.slots[s].kind == MCX_MODEL_BS);
-        reg[2 * s] = k.init_state[k.slots[s].state_off];
-        reg[2 * s + 1] = bs ? 0.0 : k.init_state[k.slots[s].state_off + 1];
+        const int kind = sig_kind(SIG, s) >= 0 ? sig_kind(SIG, s) : k.slots[s].kind;
+        const int c = k.slots[s].state_off + (kind == MCX_MODEL_S2F ? 1 : 0);      // S2F registers are (x, y) = columns 1, 2
+        if (ip) {
+            reg[2 * s] = ip[(int64_t)c * k.ld + i];
+            reg[2 * s + 1] = kind == MCX_MODEL_BS ? 0.0 : ip[(int64_t)(c + 1) * k.ld + i];
+        } else {
+            reg[2 * s] = k.init_state[c];
+            reg[2 * s + 1] = kind == MCX_MODEL_BS ? 0.0 : k.init_state[c + 1];
+        }
     }
 }
 
+// ax: aux row of the sub-step that reached date t (nullptr for the dates that hold the initial state)
 template <int NSLOT, int SIG, class KA>
-__device__ __forceinline__ void sim_store_state(const KA& k, int t, int64_t i, const double (&reg)[2 * NSLOT])
+__device__ __forceinline__ void sim_store_state(const KA& k, int t, int64_t i, const double (&reg)[2 * NSLOT],
+                                                const double* __restrict__ ax = nullptr)
 {
     const int D = k.n_state;
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) {
-        const bool bs = sig_kind(SIG, s) >= 0 ? sig_is_bs(SIG, s) : (k.slots[s].kind == MCX_MODEL_BS);
+        const int kind = sig_kind(SIG, s) >= 0 ? sig_kind(SIG, s) : k.slots[s].kind;
         const int c = k.slots[s].state_off;
+        if (kind == MCX_MODEL_S2F) {
+            // log S(t) = log F0(t) + x + y (schwartz_two_factor.py:170-171, 194-195); with a per-path start the caller's log S
+            const double logF = ax ? ldk(ax + s * MCX_AUX + 1) : k.slots[s].p[6];
+            double logS = (logF + reg[2 * s]) + reg[2 * s + 1];
+            if (!ax && k.init_paths) logS = k.init_paths[(int64_t)c * k.ld + i];
+            k.paths[((int64_t)t * D + c) * k.ld + i] = logS;
+            k.paths[((int64_t)t * D + c + 1) * k.ld + i] = reg[2 * s];
+            k.paths[((int64_t)t * D + c + 2) * k.ld + i] = reg[2 * s + 1];
+            continue;
+        }
         k.paths[((int64_t)t * D + c) * k.ld + i] = reg[2 * s];
-        if (!bs) k.paths[((int64_t)t * D + c + 1) * k.ld + i] = reg[2 * s + 1];
+        if (kind != MCX_MODEL_BS) k.paths[((int64_t)t * D + c + 1) * k.ld + i] = reg[2 * s + 1];
     }
 }

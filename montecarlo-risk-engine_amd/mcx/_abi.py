@@ -15,7 +15,7 @@ MAX_BASIS = 6
 MAX_STATES = 8
 
 SCHEME_EULER, SCHEME_MILSTEIN, SCHEME_ANALYTICAL, SCHEME_QE = 0, 1, 2, 3
-MODEL_BS, MODEL_HESTON, MODEL_VASICEK, MODEL_CIRPP, MODEL_CIRPP_DET, MODEL_HW = 1, 2, 3, 4, 5, 6
+MODEL_BS, MODEL_HESTON, MODEL_VASICEK, MODEL_CIRPP, MODEL_CIRPP_DET, MODEL_HW, MODEL_S2F = 1, 2, 3, 4, 5, 6, 7
 FLAG_SMOOTHING = 1
 LSM_MFMA, LSM_F32_CACHE = 1, 2
 EV_CASHFLOW, EV_OPTION, EV_EXERCISE, EV_EXPO_POLY, EV_EXPO_BS = 1, 2, 3, 4, 5

@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("MCX_LIB_PATH") or os.path.join(os.path.dirname(_HERE)
 
 _EXPORTS = [
     "mcx_abi_version", "mcx_create", "mcx_destroy", "mcx_last_error", "mcx_device_info",
-    "mcx_sim_create", "mcx_sim_destroy", "mcx_generate_paths", "mcx_rng_draws",
+    "mcx_sim_create", "mcx_sim_destroy", "mcx_generate_paths", "mcx_generate_paths_from_state", "mcx_rng_draws",
     "mcx_comm_unique_id", "mcx_comm_init", "mcx_comm_destroy", "mcx_allreduce_f64", "mcx_allgather_f64",
     "mcx_book_create", "mcx_book_destroy", "mcx_book_set_coeffs", "mcx_eval_book", "mcx_resolve_atoms",
     "mcx_lsm_stats", "mcx_lsm_step", "mcx_lsm_step_batch", "mcx_book_set_coeffs_batch", "mcx_book_set_bridge_rng",
@@ -116,7 +116,8 @@ class HipBackend:
         return _Owned(out, self.lib.mcx_sim_destroy, plan)
 
     def generate_paths(self, sim, seed: int, path_offset: int, n_paths: int, inject_z=None, inject_u=None,
-                       out: torch.Tensor | None = None) -> torch.Tensor:
+                       out: torch.Tensor | None = None, init_state: torch.Tensor | None = None) -> torch.Tensor:
+        """init_state [n_state][n_paths]: start every path from its own state (mcx_generate_paths_from_state)"""
         plan = sim.plan
         if out is None:
             out = self.empty(plan.n_dates, plan.n_state, n_paths)
@@ -125,10 +126,16 @@ class HipBackend:
             assert inject_z.is_contiguous() and inject_z.shape == (plan.n_steps, plan.n_z, n_paths)
         if inject_u is not None:
             assert inject_u.is_contiguous() and inject_u.shape == (plan.n_steps, n_paths)
+        zp, up = _vp(inject_z.data_ptr() if inject_z is not None else 0), _vp(inject_u.data_ptr() if inject_u is not None else 0)
+        if init_state is not None:
+            assert init_state.is_contiguous() and init_state.shape == (plan.n_state, n_paths) and init_state.is_cuda
+            self._check(self.lib.mcx_generate_paths_from_state(
+                self.h, sim.ptr, C.c_uint64(seed), C.c_uint64(path_offset), C.c_int64(n_paths), C.c_int64(n_paths),
+                _vp(init_state.data_ptr()), _vp(out.data_ptr()), zp, up, self._stream()), "mcx_generate_paths_from_state")
+            return out
         self._check(self.lib.mcx_generate_paths(
             self.h, sim.ptr, C.c_uint64(seed), C.c_uint64(path_offset), C.c_int64(n_paths), C.c_int64(n_paths),
-            _vp(out.data_ptr()), _vp(inject_z.data_ptr() if inject_z is not None else 0),
-            _vp(inject_u.data_ptr() if inject_u is not None else 0), self._stream()), "mcx_generate_paths")
+            _vp(out.data_ptr()), zp, up, self._stream()), "mcx_generate_paths")
         return out
 
     def rng_draws(self, seed: int, path0: int, n: int, step: int, draw: int):

@@ -19,7 +19,7 @@ _MODULES = [
     "metrics.metric", "metrics.risk_metrics", "metrics.pv_metric", "metrics.ce_metric", "metrics.epe_metric",
     "metrics.ene_metric", "metrics.eepe_metric", "metrics.pfe_metric", "metrics.cva_metric",
     "models.model", "models.model_config", "models.black_scholes", "models.heston", "models.vasicek", "models.cirpp",
-    "models.hull_white", "models.black_scholes_multi",
+    "models.hull_white", "models.black_scholes_multi", "models.schwartz_two_factor",
     "products.product", "products.equity", "products.bond", "products.swap", "products.european_option",
     "products.bermudan_option", "products.netting_set", "products.basket_option", "products.binary_option", "products.asian_option", "products.barrier_option", "products.flexicall",
     "request_interface.request_types", "request_interface.request_interface",

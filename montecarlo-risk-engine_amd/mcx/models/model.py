@@ -117,6 +117,38 @@ class Model:
     def resolve_request(self, req: AtomicRequest, asset_id: str, state: torch.Tensor) -> torch.Tensor:
         return self._atom(req, asset_id).evaluate(state)
 
+    # ---- one time step from a caller-supplied state (models/*.py simulate_time_step_*) ---------------------------------
+    def _simulate_time_step(self, scheme: SimulationScheme, time1, time2, state: torch.Tensor, corr_randn: torch.Tensor,
+                            uniforms: torch.Tensor | None = None) -> torch.Tensor:
+        """The reference's per-model step maps run inside the path kernel; this is that kernel on a one-step descriptor started
+        from `state` [N, state_dim] (mcx_generate_paths_from_state) with the caller's ALREADY CORRELATED normals `corr_randn`
+        [N, simulation_dim] injected (the descriptor's Cholesky factor is the identity)."""
+        from .. import _native
+        from ..plan import SimPlan
+        be = _native.get_backend()
+        t1, t2 = float(torch.as_tensor(time1).reshape(-1)[0]), float(torch.as_tensor(time2).reshape(-1)[0])
+        plan = SimPlan.single_step(self, scheme, t1, t2)
+        n = state.shape[0]
+        st = be.from_numpy(np.ascontiguousarray(state.detach().cpu().numpy().T, dtype=np.float64))          # [D][N]
+        z = be.from_numpy(np.ascontiguousarray(corr_randn.detach().cpu().numpy().T[None], dtype=np.float64))  # [1][n_z][N]
+        u = None
+        if plan.n_uniform:
+            if uniforms is None:
+                uniforms = torch.rand(n, 1, dtype=FLOAT)
+            u = be.from_numpy(np.ascontiguousarray(uniforms.detach().cpu().numpy().reshape(1, n), dtype=np.float64))
+        sim = be.sim_create(plan)
+        out = be.generate_paths(sim, 0, 0, n, inject_z=z, inject_u=u, init_state=st)                         # [1][D][N]
+        return out[0].T.to(state.device).contiguous()
+
+    def simulate_time_step_analytically(self, time1, time2, state, corr_randn):
+        return self._simulate_time_step(SimulationScheme.ANALYTICAL, time1, time2, state, corr_randn)
+
+    def simulate_time_step_euler(self, time1, time2, state, corr_randn):
+        return self._simulate_time_step(SimulationScheme.EULER, time1, time2, state, corr_randn)
+
+    def simulate_time_step_qe(self, time1, time2, state, corr_randn, uniforms=None):
+        return self._simulate_time_step(SimulationScheme.QE, time1, time2, state, corr_randn, uniforms)
+
     # ---- native hooks (overridden per family) -------------------------------------------------------------------
     def _slots(self) -> list[SlotSpec]:
         raise NotImplementedError

@@ -91,6 +91,21 @@ class SimPlan:
     def path_steps_per_path(self) -> int:
         return self.n_steps
 
+    @classmethod
+    def single_step(cls, model, scheme: SimulationScheme, t1: float, t2: float) -> "SimPlan":
+        """the one sub-step [t1, t2] with an identity Cholesky factor: Model.simulate_time_step_*(time1, time2, state, corr_randn)
+        receives normals that are already correlated (model.py:38-48 applies the factor before the step)"""
+        plan = cls(model, np.array([t2]), scheme, 1)
+        if plan.n_steps != 1:
+            raise ValueError("time2 must lie after the calibration date")
+        dt = float(t2) - float(t1)
+        plan.steps["dt"], plan.steps["sqrt_dt"], plan.steps["t1"] = dt, math.sqrt(dt), float(t1)
+        plan.aux[:] = 0.0
+        for s, vals in enumerate(model._step_aux(scheme, float(t1), dt)):
+            plan.aux[0, s, :len(vals)] = vals
+        plan.chol[:] = np.eye(plan.n_z)[None]
+        return plan
+
 
 class BookCompiler:
     """Accumulates atoms / terms / events while products and metrics describe themselves."""

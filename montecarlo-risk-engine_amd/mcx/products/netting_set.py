@@ -51,10 +51,41 @@ class NettingSet:
         return torch.where(exposures > h, exposures - h,
                            torch.where(exposures < -h, exposures + h, torch.zeros_like(exposures)))
 
+    def _exposure_at(self, netted_exposures: torch.Tensor, exposure_timeline: torch.Tensor, query_times: torch.Tensor):
+        """netted exposure rows looked up at arbitrary times (netting_set.py:76-107): the last grid date at or before the query
+        ('previous') or the straight line between the two neighbouring grid dates ('linear'); zero before the first grid date,
+        flat after the last one"""
+        if netted_exposures.numel() == 0:
+            return netted_exposures
+        last = exposure_timeline.shape[0] - 1
+        early = (query_times < exposure_timeline[0]).unsqueeze(1)
+        if self.collateral_interpolation == "previous":
+            at = (torch.searchsorted(exposure_timeline, query_times, right=True) - 1).clamp(0, last)
+            vals = netted_exposures.index_select(0, at)
+        else:
+            hi = torch.searchsorted(exposure_timeline, query_times).clamp(max=last)
+            lo = (hi - 1).clamp(min=0)
+            t_lo, t_hi = exposure_timeline.index_select(0, lo), exposure_timeline.index_select(0, hi)
+            span = t_hi - t_lo
+            w = torch.where(span > 0.0, (query_times - t_lo) / span, torch.zeros_like(query_times)).unsqueeze(1)
+            v_lo = netted_exposures.index_select(0, lo)
+            vals = v_lo + w * (netted_exposures.index_select(0, hi) - v_lo)
+        return torch.where(early, torch.zeros_like(vals), vals)
+
     def compute_collateral_profile(self, netted_exposures, exposure_timeline, metric_exposure_indices=None,
                                    delayed_exposure_indices=None):
         if metric_exposure_indices is None or delayed_exposure_indices is None:
-            raise NotImplementedError("collateral profiles are evaluated on exact delayed exposure indices")
+            # no exact delayed grid dates: the collateral call is the thresholded exposure interpolated at t - MPoR
+            # (netting_set.py:151-157).  SimulationController never takes this branch (its internal grid contains every
+            # delayed date, controller.py:153-162); it is API parity for direct callers of the Metrics API
+            if metric_exposure_indices is not None:
+                rows = netted_exposures.index_select(0, metric_exposure_indices)
+                if not self.is_collateralized() or netted_exposures.numel() == 0:
+                    return torch.zeros_like(rows)
+            if not self.is_collateralized() or netted_exposures.numel() == 0:
+                return torch.zeros_like(netted_exposures)
+            delayed = self._exposure_at(netted_exposures, exposure_timeline, exposure_timeline - self.margin_period_of_risk)
+            return self.apply_threshold(delayed)
         rows = netted_exposures.index_select(0, metric_exposure_indices)
         out = torch.zeros_like(rows)
         if not self.is_collateralized() or netted_exposures.numel() == 0:

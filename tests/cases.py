@@ -50,6 +50,14 @@ def bs_european():
     return [NettingSet(name=prod.get_name(), products=[prod])], model, RiskMetrics([PVMetric()])
 
 
+def s2f_european():
+    from mcx.models.schwartz_two_factor import SchwartzTwoFactorModel
+    model = SchwartzTwoFactorModel(0.0, [0.0, 0.5, 1.0, 2.0], [30.0, 32.0, 31.0, 29.0], rate=0.03, short_term_mean_reversion=1.5,
+                                   short_term_vol=0.4, long_term_drift=0.01, long_term_vol=0.15, rho=0.3, asset_id="gas")
+    prod = EuropeanOption(Equity("gas"), 1.0, 30.0, OptionType.CALL)
+    return [NettingSet(name=prod.get_name(), products=[prod])], model, RiskMetrics([PVMetric()])
+
+
 def bs_put_euler():
     model = BlackScholesModel(0, 90.0, 0.03, 0.35)
     prod = EuropeanOption(Equity(), 1.5, 100.0, OptionType.PUT)
@@ -296,6 +304,8 @@ CASES = {
     "barrier_bridge": (barrier_bridge, 0, 2048, 2, A, False),
     "flexicall": (flexicall, 2048, 1024, 1, A, False),
     "mixed_book_multi": (mixed_book_multi, 128, 128, 1, E, False),
+    "s2f_european": (s2f_european, 0, 1024, 4, A, False),
+    "s2f_european_euler": (s2f_european, 0, 1024, 6, E, False),
     # sensitivities through the LSM regression; the fixtures hold only the reference gradients, draws = the base case's
     "irs_cva_aad": (irs_cva, 1024, 1024, 2, E, True),
     "mixed_cva_aad": (mixed_cva, 512, 512, 2, E, True),

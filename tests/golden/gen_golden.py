@@ -592,10 +592,62 @@ def case_bs_european_exposure():
     return ns, model, RiskMetrics([EPEMetric(), PFEMetric(0.9), PVMetric()], exposure_timeline=tl)
 
 
+def case_s2f_european():
+    """Schwartz two-factor commodity model (models/schwartz_two_factor.py:147-196): European call on the spot"""
+    from models.schwartz_two_factor import SchwartzTwoFactorModel
+    model = SchwartzTwoFactorModel(0.0, [0.0, 0.5, 1.0, 2.0], [30.0, 32.0, 31.0, 29.0], rate=0.03, short_term_mean_reversion=1.5,
+                                   short_term_vol=0.4, long_term_drift=0.01, long_term_vol=0.15, rho=0.3, asset_id="gas")
+    prod = EuropeanOption(Equity("gas"), 1.0, 30.0, OptionType.CALL)
+    return [NettingSet(name=prod.get_name(), products=[prod])], model, RiskMetrics([PVMetric()])
+
+
+def gen_netting_interp():
+    """NettingSet collateral profile WITHOUT exact delayed indices (netting_set.py:76-107, 151-157): 'linear' and 'previous'
+    interpolation of the netted exposure at t - MPoR, with and without a threshold"""
+    g = torch.Generator().manual_seed(11)
+    tl = torch.tensor([0.0, 0.25, 0.5, 1.0, 1.5, 2.5], dtype=torch.float64)
+    expo = torch.randn(6, 64, generator=g, dtype=torch.float64) * 3.0
+    prod = EuropeanOption(Equity("eq"), 1.0, 100.0, OptionType.CALL)
+    out = {"timeline": tl.numpy(), "expo": expo.numpy()}
+    for mode in ("linear", "previous"):
+        for thr in (0.0, 0.75):
+            for mpor in (0.1, 0.25, 0.6):
+                ns = NettingSet(name="c", products=[prod], threshold=thr, margin_period_of_risk=mpor, collateral_interpolation=mode)
+                key = f"{mode}_{thr}_{mpor}"
+                out["coll_" + key] = npf(ns.compute_collateral_profile(expo, tl))
+                out["unsec_" + key] = npf(ns.compute_unsecured_exposure_profiles(expo, tl))
+    path = os.path.join(OUT, "netting_interp.npz")
+    np.savez_compressed(path, **out)
+    print("netting_interp: wrote", path)
+
+
+def slim_to_gradients(name):
+    """a differentiate=True fixture of a case whose draws / paths are already held by the base fixture: keep the results,
+    the reference's autograd gradients and the names only"""
+    path = os.path.join(OUT, name + ".npz")
+    g = np.load(path)
+    keep = {k: g[k] for k in g.files if k.startswith(("result_", "grad_")) or k in ("param_names", "metric_names", "netting_set_names")}
+    np.savez_compressed(path, **keep)
+    print(f"{name}: slimmed to {os.path.getsize(path)/1024:.0f} KiB")
+
+
+NEW_CASES = {
+    # round 2: Schwartz two-factor; sensitivities of exercise products (the tape freezes the exercise decisions, bermudan_option.py:122-128)
+    "s2f_european": lambda: run_controller_case("s2f_european", case_s2f_european, 0, 1024, 4, SimulationScheme.ANALYTICAL),
+    "s2f_european_euler": lambda: run_controller_case("s2f_european_euler", case_s2f_european, 0, 1024, 6, SimulationScheme.EULER),
+    "bermudan_swaption_aad": lambda: (run_controller_case("bermudan_swaption_aad", case_bermudan_swaption, 1024, 1024, 1, SimulationScheme.EULER, differentiate=True),
+                                      slim_to_gradients("bermudan_swaption_aad")),
+    "american_put_aad": lambda: (run_controller_case("american_put_aad", case_american, 2048, 1024, 1, SimulationScheme.ANALYTICAL, differentiate=True),
+                                 slim_to_gradients("american_put_aad")),
+    "netting_interp": gen_netting_interp,
+}
+
+
 def main():
     torch.set_num_threads(4)
-    if len(sys.argv) > 1 and sys.argv[1] == "new":
-        run_controller_case("barrier_bridge", case_barrier_bridge, 0, 2048, 2, SimulationScheme.ANALYTICAL, extra=_bridge_extra)
+    if len(sys.argv) > 1 and sys.argv[1] == "only":           # python gen_golden.py only <case> [<case> ...]
+        for n in sys.argv[2:]:
+            NEW_CASES[n]()
         return
     gen_steps()
     gen_paths_mc4()
@@ -631,6 +683,8 @@ def main():
     run_controller_case("flexicall", case_flexicall, 2048, 1024, 1, A)
     run_controller_case("mixed_book_multi", case_mixed_book_multi, 128, 128, 1, E)
     run_controller_case("barrier_bridge", case_barrier_bridge, 0, 2048, 2, A, extra=_bridge_extra)
+    for fn in NEW_CASES.values():
+        fn()
 
 
 if __name__ == "__main__":

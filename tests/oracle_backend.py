@@ -70,10 +70,15 @@ class OracleBackend:
     def sim_create(self, plan):
         return _Obj(plan)
 
-    def generate_paths(self, sim, seed, path_offset, n_paths, inject_z=None, inject_u=None, out=None):
+    def generate_paths(self, sim, seed, path_offset, n_paths, inject_z=None, inject_u=None, out=None, init_state=None):
         plan = sim.plan
         if out is None:
             out = torch.empty(plan.n_dates, plan.n_state, n_paths, dtype=torch.float64)
+        if init_state is not None:
+            rc = self.lib.orc_generate_paths_from_state(C.byref(plan.desc), C.c_uint64(seed), C.c_uint64(path_offset), C.c_int64(n_paths),
+                                                        C.c_int64(n_paths), _p(init_state), _p(out), _p(inject_z), _p(inject_u))
+            assert rc == 0
+            return out
         rc = self.lib.orc_generate_paths(C.byref(plan.desc), C.c_uint64(seed), C.c_uint64(path_offset), C.c_int64(n_paths),
                                          C.c_int64(n_paths), _p(out), _p(inject_z), _p(inject_u))
         assert rc == 0

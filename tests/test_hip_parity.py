@@ -399,6 +399,12 @@ def test_rccl_collectives_single_rank_group(hip):
     assert a[0] == b[0]
 
 
+def test_simulate_time_step_api_on_the_gpu(hip):
+    """the reference's Model.simulate_time_step_* signature served by mcx_generate_paths_from_state (per-path start states)"""
+    from test_oracle_units import check_simulate_time_step_api
+    check_simulate_time_step_api(hip)
+
+
 def test_comm_entry_points_single_rank(hip):
     """mcx_comm_* of the C ABI (RCCL loaded with dlopen): a one-rank communicator, all-reduce and all-gather of device buffers"""
     uid = hip.comm_unique_id()

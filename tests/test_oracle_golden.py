@@ -106,3 +106,19 @@ def test_lsm_sensitivities_against_reference_autograd(name, oracle):
     sc, g = cases.make_controller(name, oracle)
     res = sc.run_simulation()
     check_lsm_sensitivities(sc, g, res)
+
+
+def test_netting_set_interpolated_collateral_matches_reference():
+    """NettingSet.compute_collateral_profile / compute_unsecured_exposure_profiles without exact delayed indices
+    (netting_set.py:76-107, 151-157): values recorded from the reference for 'linear' / 'previous', thresholds, three MPoRs"""
+    g = cases.load_golden("netting_interp")
+    tl, expo = torch.from_numpy(g["timeline"]), torch.from_numpy(g["expo"])
+    prod = cases.EuropeanOption(cases.Equity("eq"), 1.0, 100.0, cases.OptionType.CALL)
+    n = 0
+    for key in [k[5:] for k in g.files if k.startswith("coll_")]:
+        mode, thr, mpor = key.split("_")
+        ns = cases.NettingSet(name="c", products=[prod], threshold=float(thr), margin_period_of_risk=float(mpor), collateral_interpolation=mode)
+        assert np.allclose(ns.compute_collateral_profile(expo, tl).numpy(), g["coll_" + key], rtol=1e-14, atol=1e-14), key
+        assert np.allclose(ns.compute_unsecured_exposure_profiles(expo, tl).numpy(), g["unsec_" + key], rtol=1e-14, atol=1e-14), key
+        n += 1
+    assert n == 12

@@ -91,6 +91,44 @@ def test_step_maps_match_reference(oracle):
         assert np.allclose(got, G[f"he2_qe_{tag}"], rtol=1e-10, atol=1e-13), tag
 
 
+def check_simulate_time_step_api(backend):
+    """Model.simulate_time_step_{analytically,euler,qe}(time1, time2, state, corr_randn) — the reference's signature
+    (models/vasicek.py:61-112, cirpp.py:174-198, heston.py:99-253) — through mcx_generate_paths_from_state on `backend`:
+    per-path start states and caller-correlated normals, against the step maps recorded from the reference"""
+    from mcx import _native
+    A, E, Q = SimulationScheme.ANALYTICAL, SimulationScheme.EULER, SimulationScheme.QE
+    t1, t2 = torch.tensor(float(G["t1"][0]), dtype=torch.float64), torch.tensor(float(G["t2"][0]), dtype=torch.float64)
+    dt = float(t2 - t1)
+    prev = _native._default_backend
+    _native.set_backend(backend)
+    try:
+        def run(model, scheme, state, z, name, u=None):
+            corr = torch.from_numpy(z) @ model.get_cholesky(scheme, dt).T
+            st = torch.from_numpy(state)
+            if scheme == Q:
+                return model.simulate_time_step_qe(t1, t2, st, corr, torch.from_numpy(u)).cpu().numpy()
+            fn = model.simulate_time_step_analytically if scheme == A else model.simulate_time_step_euler
+            return fn(t1, t2, st, corr).cpu().numpy()
+        bs = BlackScholesModel(0.0, 120.0, 0.05, 0.2)
+        assert np.allclose(run(bs, A, G["bs_state"], G["bs_z"], "bs"), G["bs_exact"], rtol=1e-12)
+        assert np.allclose(run(bs, E, G["bs_state"], G["bs_z"], "bs"), G["bs_euler"], rtol=1e-12)
+        va = VasicekModel(0.0, 0.03, 0.05, 0.1, 0.01, asset_id="irs")
+        assert np.allclose(run(va, A, G["va_state"], G["va_z"], "va"), G["va_exact"], rtol=1e-11, atol=1e-14)
+        assert np.allclose(run(va, E, G["va_state"], G["va_z"], "va"), G["va_euler"], rtol=1e-11, atol=1e-14)
+        ci = CIRPPModel(0.0, "cp", cases.HAZARDS, 0.1, 0.01, 0.02, 1e-4)
+        assert np.allclose(run(ci, E, G["ci_state"], G["ci_z"], "ci"), G["ci_euler"], rtol=1e-11, atol=1e-15)
+        he = HestonModel(0.0, 800.0, 0.04, 0.45545583, -0.78975708, 0.01713417, 2.0, 0.0286834)
+        assert np.allclose(run(he, E, G["he_state"], G["he_z"], "he"), G["he_euler"], rtol=1e-11, atol=1e-14)
+        got = run(he, Q, G["he_state"], G["he_z"], "he", G["he_qe_hard_u"])
+        assert np.allclose(got, G["he_qe_hard"], rtol=1e-10, atol=1e-13)
+    finally:
+        _native.set_backend(prev)
+
+
+def test_simulate_time_step_api_matches_reference(oracle):
+    check_simulate_time_step_api(oracle)
+
+
 def test_closed_forms_and_cholesky_match_reference():
     ci = CIRPPModel(0.0, "cp", cases.HAZARDS, 0.1, 0.01, 0.02, 1e-4)
     assert np.allclose([ci.psi(t) for t in G["ci_times"]], G["ci_psi"], rtol=1e-13)

@@ -9,7 +9,6 @@ Not run, with the reason:
                                      their tolerances equal ~1 Monte-Carlo standard error of the estimate (they pass or fail
                                      with the luck of the stream: 1.6 sigma off with the Philox stream); the same anchors are
                                      asserted at 3-4 sigma in test_hip_parity.py
-  test_cirpp.py                      calls Model.simulate_time_step_euler directly (the per-step maps live in the kernels)
   test_single_product_executor_parity.py, test_storage*.py, test_t_cdf_autograd.py
                                      gas storage / notebook helpers (out of scope); the single-product sweep is
                                      tests/test_single_products.py"""
@@ -25,7 +24,8 @@ import cases
 
 REF = "/root/reference/tests/pytests"
 MODULES = ["test_cva.py", "test_netting_sets.py", "test_pv_european_option_heston.py", "test_simulation_results_named_access.py",
-           "test_european_option_hessian.py", "test_cva_large_netting_set_aad_vs_fd.py", "test_cva_large_netting_set_surface.py"]
+           "test_european_option_hessian.py", "test_cva_large_netting_set_aad_vs_fd.py", "test_cva_large_netting_set_surface.py",
+           "test_cirpp.py"]          # calls Model.simulate_time_step_euler directly: served by mcx_generate_paths_from_state
 
 pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree is only mounted in the build container")
 
