@@ -396,6 +396,23 @@ int  mcx_lsm_step(mcx_handle* h, const mcx_book* book, int32_t product, int32_t 
                   const double* d_paths, int64_t n_paths, int64_t ld,
                   double* d_W, int64_t ld_w, double* d_moments, int32_t flags, void* stream);
 
+/* The whole backward induction of ONE product on the device: for every date of h_dates, in order, the roll + moments of
+ * mcx_lsm_step, the (rank-aware) K x K solve and the scatter of the [n_states][K] coefficient block into the book's coefficient
+ * array (where the next date's exercise decisions read it) are enqueued back to back on the stream — no host round trip per date
+ * (controller.py:294-383 is a Python loop with one lstsq per date).  With a communicator on the handle (mcx_comm_init) the moments
+ * are all-reduced over the ranks between roll and solve, also stream-ordered.  h_coeffs [n_dates][n_states][K] receives the
+ * coefficients; h_status[d] != 0 marks a numerically singular system (its coefficients were NOT written: the caller re-solves
+ * that product with mcx_lsm_step and its own solver).  degenerate / x0: every path shares x = x0 (minimum-norm rank-1 solution). */
+typedef struct {
+    int32_t roll_begin, roll_end, num_atom, x_atom;
+    int32_t degenerate, reserved;
+    int64_t coeff_off[2];   /* offsets of the date's coefficient block in the book's coefficient array, -1 = none        */
+    double  shift, scale, x0;
+} mcx_lsm_date;
+int  mcx_lsm_run(mcx_handle* h, mcx_book* book, int32_t product, const mcx_lsm_date* h_dates, int32_t n_dates,
+                 const double* d_paths, int64_t n_paths, int64_t ld, double* d_W, int64_t ld_w,
+                 double* h_coeffs, int32_t* h_status, int32_t flags, void* stream);
+
 /* Product-batched LSM step (books of thousands of products: tests/exposure_tests/cva_perfprmance_large_netting_set.py): the
  * step of mcx_lsm_step for n_jobs products with the SAME number of exercise states in one launch.  Job j uses the cashflow
  * cache block d_W + w_offset (layout [n_states][ld_w]) and returns its moments in h_moments[j * NM .. ), NM = (2K-1) + S*K

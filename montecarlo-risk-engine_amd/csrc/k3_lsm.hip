@@ -3,7 +3,8 @@
 // Replaces one iteration of the reference's backward loop (controller/controller.py:316-383): roll the cached future
 // cashflows one window back along the exercise policy (cf_cache, :325-352), multiply by the numeraire at the regression
 // date (:368) and form the normal equations of the monomial regression that torch.linalg.lstsq solves (:370-374).
-// The K x K solve (K <= 6) happens on the host after the cross-GPU all-reduce of the moments.
+// The K x K solve (K <= 6): on the host after the cross-GPU all-reduce of the moments (mcx_lsm_step), or on the device with the
+// whole backward induction of a product enqueued back to back (mcx_lsm_run: no host round trip per date).
 //
 // Two moment kernels:
 //   * VALU + wave64 shuffle reduction (default): each lane keeps the 2K-1 + S*K running sums of its paths in VGPRs;
@@ -37,9 +38,15 @@ __device__ __forceinline__ double k3_poly(const double* __restrict__ c, int K, d
     return v;
 }
 
-__device__ __forceinline__ double k3_cash_event(const DevEvent& e, const K3Args& a, int64_t D, int64_t i, int& s)
+// value of one cash event for path i.  Every kind but EXERCISE is independent of the product's exercise state; for an EXERCISE
+// event the function returns the state-independent pieces (immediate value `imm`, numeraire `num`, explanatory variable `x`) and
+// sets `exercise`: the decision per hypothetical state is k3_exercise() — the 64-term swap value of a Bermudan swaption is then
+// evaluated ONCE per path and date, not once per state.
+__device__ __forceinline__ double k3_cash_event(const DevEvent& e, const K3Args& a, int64_t D, int64_t i, bool& exercise, double& imm,
+                                                double& num, double& x)
 {
-    const double num = dev_atom(e.num, a.paths, D, a.ld, i);
+    exercise = false;
+    num = dev_atom(e.num, a.paths, D, a.ld, i);
     double common = 0.0, own = 0.0, glog = 0.0;
     if (e.kind == MCX_EV_OPTION && (e.aux[0] == 4.0 || e.aux[0] == 5.0))      // barrier options (barrier_option.py:60-223)
         return dev_barrier_event(e, a.terms, a.coeffs, a.bridge, a.paths, D, a.ld, i, num);
@@ -64,16 +71,22 @@ __device__ __forceinline__ double k3_cash_event(const DevEvent& e, const K3Args&
         else own += v / dev_atom(ldk_struct(&a.atoms[tm.den]), a.paths, D, a.ld, i);
     }
     if (e.kind == MCX_EV_CASHFLOW) return common / num + own;
-    const double imm = fmax(e.sign * (common - e.strike), 0.0);
+    imm = fmax(e.sign * (common - e.strike), 0.0);
     if (basket) {
         const double geo = fmax(e.sign * (mcx_exp(glog) - e.strike), 0.0);
         return (e.aux[0] == 1.0 ? geo : imm - geo + e.aux[1]) / num;
     }
     if (e.kind == MCX_EV_OPTION) return imm / num;
-    double cont = 0.0;
-    double cont_ex = 0.0;                                     // flexicall.py:118-133 (aux[0] = 1)
+    exercise = true;
+    x = e.coeff_off >= 0 ? dev_atom(e.x, a.paths, D, a.ld, i) : 0.0;
+    return 0.0;
+}
+
+// exercise decision of one hypothetical state s (bermudan_option.py:93-131, flexicall.py:118-133 for aux[0] = 1)
+__device__ __forceinline__ double k3_exercise(const DevEvent& e, const K3Args& a, double imm, double num, double x, int& s)
+{
+    double cont = 0.0, cont_ex = 0.0;
     if (e.coeff_off >= 0) {
-        const double x = dev_atom(e.x, a.paths, D, a.ld, i);
         cont = k3_poly(a.coeffs + e.coeff_off + s * a.n_basis, a.n_basis, x);
         if (e.aux[0] == 1.0 && s > 0) cont_ex = k3_poly(a.coeffs + e.coeff_off + (s - 1) * a.n_basis, a.n_basis, x);
     }
@@ -91,19 +104,28 @@ __device__ __forceinline__ void k3_roll(const K3Args& a, int64_t i, double (&y)[
 #pragma unroll
     for (int s = 0; s < S; ++s) w[s] = a.W[(int64_t)s * a.ld_w + i];
     if (a.roll_end > a.roll_begin) {
+        int st[S];
+        double sv[S];
+#pragma unroll
+        for (int s0 = 0; s0 < S; ++s0) { st[s0] = s0; sv[s0] = 0.0; }
+        for (int q = a.roll_begin; q < a.roll_end; ++q) {                   // controller.py:333-341
+            const DevEvent e = ldk_struct(&a.events[q]);
+            bool exercise;
+            double imm = 0.0, num = 1.0, x = 0.0;
+            const double v = k3_cash_event(e, a, D, i, exercise, imm, num, x);
+#pragma unroll
+            for (int s0 = 0; s0 < S; ++s0) {
+                sv[s0] += exercise ? k3_exercise(e, a, imm, num, x, st[s0]) : v;
+                if (a.f32_cache) sv[s0] = (double)(float)sv[s0];             // float32 cf_cache quirk (controller.py:312-330)
+            }
+        }
         double wn[S];
 #pragma unroll
         for (int s0 = 0; s0 < S; ++s0) {
-            int s = s0;
-            double step_value = 0.0;
-            for (int q = a.roll_begin; q < a.roll_end; ++q) {               // controller.py:333-341
-                step_value += k3_cash_event(ldk_struct(&a.events[q]), a, D, i, s);
-                if (a.f32_cache) step_value = (double)(float)step_value;     // float32 cf_cache quirk (controller.py:312-330)
-            }
             double tail = w[0];
 #pragma unroll
-            for (int q = 1; q < S; ++q) tail = (s == q) ? w[q] : tail;       // lookup_state_values (product.py:150-155)
-            const double total = step_value + tail;
+            for (int q = 1; q < S; ++q) tail = (st[s0] == q) ? w[q] : tail;  // lookup_state_values (product.py:150-155)
+            const double total = sv[s0] + tail;
             wn[s0] = a.f32_cache ? (double)(float)total : total;
         }
 #pragma unroll
@@ -312,6 +334,87 @@ __global__ void k3_minmax_finish(const double* __restrict__ partials, int n_bloc
     if (threadIdx.x == 0) { out[2 * q] = lo; out[2 * q + 1] = hi; }
 }
 
+// ---- device-side normal-equation solve (mcx_lsm_run) ---------------------------------------------------------------------
+// One date of the backward induction: moments of the shifted / scaled basis -> least-squares coefficients in the RAW monomial
+// basis, written straight into the book's coefficient array (what the next date's roll reads) and into the result table.
+// Same algorithm as the host solver (mcx/plan.py solve_normal_equations): LU with partial pivoting of the K x K Gram matrix,
+// back-transformation z^k = scale^k (x - shift)^k, and the minimum-norm solution of the exactly rank-1 system of a date on
+// which every path shares x = x0 (the calibration date).  K <= 6, S <= 8: one lane.
+struct K3Solve {
+    double shift, scale, x0;
+    int64_t off0, off1;          // coefficient offsets in the book (-1: none)
+    int32_t degenerate, K, S, date;
+};
+
+__global__ void k3_solve(const double* __restrict__ m, const K3Solve q, double* __restrict__ coeffs, double* __restrict__ table,
+                         int32_t* __restrict__ status)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int K = q.K, S = q.S;
+    double out[MCX_MAX_STATES][MCX_MAX_BASIS];
+    for (int s = 0; s < S; ++s) for (int k = 0; k < K; ++k) out[s][k] = 0.0;
+    const double n = m[0];
+    int st = 0;
+    if (n > 0.0 && q.degenerate) {
+        double v[MCX_MAX_BASIS], vv = 0.0, xp = 1.0;
+        for (int k = 0; k < K; ++k) { v[k] = xp; vv += xp * xp; xp *= q.x0; }
+        for (int s = 0; s < S; ++s) {
+            const double mean_y = m[(2 * K - 1) + s * K] / n;
+            for (int k = 0; k < K; ++k) out[s][k] = v[k] * (mean_y / vv);
+        }
+    } else if (n > 0.0) {
+        double G[MCX_MAX_BASIS][MCX_MAX_BASIS], B[MCX_MAX_BASIS][MCX_MAX_STATES];
+        double gmax = 0.0;
+        for (int j = 0; j < K; ++j) for (int k = 0; k < K; ++k) { G[j][k] = m[j + k]; gmax = fmax(gmax, fabs(G[j][k])); }
+        for (int k = 0; k < K; ++k) for (int s = 0; s < S; ++s) B[k][s] = m[(2 * K - 1) + s * K + k];
+        for (int c = 0; c < K; ++c) {                                  // LU, partial pivoting (as LAPACK dgesv)
+            int piv = c;
+            for (int r = c + 1; r < K; ++r) if (fabs(G[r][c]) > fabs(G[piv][c])) piv = r;
+            if (!(fabs(G[piv][c]) > 1e-14 * gmax)) { st = 1; break; }  // numerically singular: the caller re-solves on the host
+            if (piv != c) {
+                for (int k = 0; k < K; ++k) { const double t = G[c][k]; G[c][k] = G[piv][k]; G[piv][k] = t; }
+                for (int s = 0; s < S; ++s) { const double t = B[c][s]; B[c][s] = B[piv][s]; B[piv][s] = t; }
+            }
+            for (int r = c + 1; r < K; ++r) {
+                const double f = G[r][c] / G[c][c];
+                for (int k = c + 1; k < K; ++k) G[r][k] -= f * G[c][k];
+                for (int s = 0; s < S; ++s) B[r][s] -= f * B[c][s];
+            }
+        }
+        if (st == 0) {
+            for (int c = K - 1; c >= 0; --c)
+                for (int s = 0; s < S; ++s) {
+                    double acc = B[c][s];
+                    for (int k = c + 1; k < K; ++k) acc -= G[c][k] * B[k][s];
+                    B[c][s] = acc / G[c][c];
+                }
+            // T[j][k] = coefficient of x^j in z^k = scale^k C(k, j) (-shift)^(k-j)
+            double sp = 1.0;
+            for (int k = 0; k < K; ++k) {
+                double binom = 1.0;
+                for (int j = 0; j <= k; ++j) {
+                    double ms = 1.0;
+                    for (int e = 0; e < k - j; ++e) ms *= -q.shift;
+                    const double T = sp * binom * ms;
+                    for (int s = 0; s < S; ++s) out[s][j] += T * B[k][s];
+                    binom = binom * (double)(k - j) / (double)(j + 1);
+                }
+                sp *= q.scale;
+            }
+        }
+    }
+    status[q.date] = st;
+    for (int s = 0; s < S; ++s)
+        for (int k = 0; k < K; ++k) {
+            const double c = out[s][k];
+            table[((int64_t)q.date * S + s) * K + k] = c;
+            if (st == 0) {
+                if (q.off0 >= 0) coeffs[q.off0 + s * K + k] = c;
+                if (q.off1 >= 0) coeffs[q.off1 + s * K + k] = c;
+            }
+        }
+}
+
 template <int K, int S>
 void launch_k3(const K3Args& a, int grid, bool mfma, hipStream_t s)
 {
@@ -378,23 +481,22 @@ extern "C" int mcx_lsm_stats(mcx_handle* h, const mcx_book* b, const int32_t* h_
     return 0;
 }
 
-extern "C" int mcx_lsm_step(mcx_handle* h, const mcx_book* b, int32_t product, int32_t roll_begin, int32_t roll_end, int32_t num_atom,
-                            int32_t x_atom, double shift, double scale, const double* d_paths, int64_t n_paths, int64_t ld,
-                            double* d_W, int64_t ld_w, double* d_moments, int32_t flags, void* stream)
+// roll + moments of one (product, date) on the stream: d_moments[NM] (device)
+static int lsm_step_launch(mcx_handle* h, const mcx_book* b, int32_t product, int32_t roll_begin, int32_t roll_end, int32_t num_atom,
+                           int32_t x_atom, double shift, double scale, const double* d_paths, int64_t n_paths, int64_t ld,
+                           double* d_W, int64_t ld_w, double* d_moments, int32_t flags, hipStream_t s, const char* who)
 {
-    if (!h || !b || !d_paths || !d_W || !d_moments) return -1;
-    if (product < 0 || product >= b->n_products) MCX_FAIL(h, -2, "mcx_lsm_step: product out of range");
+    if (product < 0 || product >= b->n_products) MCX_FAIL(h, -2, "%s: product out of range", who);
     const DevProduct& pr = b->h_products[product];
     const int n_cf = pr.cf_end - pr.cf_begin;
-    if (roll_begin < 0 || roll_end < roll_begin || roll_end > n_cf) MCX_FAIL(h, -2, "mcx_lsm_step: roll window out of range");
-    if (num_atom < 0 || num_atom >= b->n_atoms || x_atom < 0 || x_atom >= b->n_atoms) MCX_FAIL(h, -2, "mcx_lsm_step: atom out of range");
-    if (ld < n_paths || ld_w < n_paths) MCX_FAIL(h, -2, "mcx_lsm_step: leading dimension < n_paths");
+    if (roll_begin < 0 || roll_end < roll_begin || roll_end > n_cf) MCX_FAIL(h, -2, "%s: roll window out of range", who);
+    if (num_atom < 0 || num_atom >= b->n_atoms || x_atom < 0 || x_atom >= b->n_atoms) MCX_FAIL(h, -2, "%s: atom out of range", who);
+    if (ld < n_paths || ld_w < n_paths) MCX_FAIL(h, -2, "%s: leading dimension < n_paths", who);
     const int K = b->n_basis, S = pr.n_states;
     const int NM = (2 * K - 1) + S * K;
-    hipStream_t s = (hipStream_t)stream;
     if (n_paths <= 0) { MCX_HIP(h, hipMemsetAsync(d_moments, 0, sizeof(double) * NM, s)); return 0; }
     const int grid = mcx_grid_for(n_paths, MCX_BLOCK, 4 * h->n_cu);
-    if ((size_t)grid * NM * sizeof(double) > h->ws_bytes) MCX_FAIL(h, -2, "mcx_lsm_step: workspace too small");
+    if ((size_t)grid * NM * sizeof(double) > h->ws_bytes) MCX_FAIL(h, -2, "%s: workspace too small", who);
     auto flat = [&](int id) { DevAtom o; const mcx_atom& q = b->h_atoms[id]; o.t_idx = q.t_idx; o.col = q.col; o.a = q.a; o.d = q.d; o.b = q.b; o.c0 = q.c0; o.c1 = q.c1; return o; };
     K3Args a;
     a.terms = b->d_terms; a.events = b->d_events + pr.cf_begin; a.atoms = b->d_atoms; a.coeffs = b->d_coeffs; a.paths = d_paths;
@@ -414,11 +516,60 @@ extern "C" int mcx_lsm_step(mcx_handle* h, const mcx_book* b, int32_t product, i
     case 8: rc = dispatch_k3<8>(K, a, grid, mfma, s); break;
     default: break;
     }
-    if (rc != 0) MCX_FAIL(h, -3, "mcx_lsm_step: unsupported (basis=%d, states=%d)", K, S);
+    if (rc != 0) MCX_FAIL(h, -3, "%s: unsupported (basis=%d, states=%d)", who, K, S);
     MCX_HIP(h, hipGetLastError());
     hipLaunchKernelGGL(k3_finish, dim3(NM), dim3(MCX_BLOCK), 0, s, h->d_ws, NM, grid, d_moments);
     MCX_HIP(h, hipGetLastError());
     return 0;
+}
+
+extern "C" int mcx_lsm_step(mcx_handle* h, const mcx_book* b, int32_t product, int32_t roll_begin, int32_t roll_end, int32_t num_atom,
+                            int32_t x_atom, double shift, double scale, const double* d_paths, int64_t n_paths, int64_t ld,
+                            double* d_W, int64_t ld_w, double* d_moments, int32_t flags, void* stream)
+{
+    if (!h || !b || !d_paths || !d_W || !d_moments) return -1;
+    return lsm_step_launch(h, b, product, roll_begin, roll_end, num_atom, x_atom, shift, scale, d_paths, n_paths, ld, d_W, ld_w,
+                           d_moments, flags, (hipStream_t)stream, "mcx_lsm_step");
+}
+
+extern "C" int mcx_lsm_run(mcx_handle* h, mcx_book* b, int32_t product, const mcx_lsm_date* h_dates, int32_t n_dates,
+                           const double* d_paths, int64_t n_paths, int64_t ld, double* d_W, int64_t ld_w,
+                           double* h_coeffs, int32_t* h_status, int32_t flags, void* stream)
+{
+    if (!h || !b || !h_dates || !d_paths || !d_W || !h_coeffs || !h_status) return -1;
+    if (n_dates <= 0) return 0;
+    if (product < 0 || product >= b->n_products) MCX_FAIL(h, -2, "mcx_lsm_run: product out of range");
+    const int K = b->n_basis, S = b->h_products[product].n_states, NM = (2 * K - 1) + S * K;
+    const size_t tab_bytes = sizeof(double) * (size_t)n_dates * S * K, st_bytes = sizeof(int32_t) * (size_t)n_dates;
+    for (int d = 0; d < n_dates; ++d)
+        for (int w = 0; w < 2; ++w)
+            if (h_dates[d].coeff_off[w] >= 0 && h_dates[d].coeff_off[w] + (int64_t)S * K > b->n_coeffs)
+                MCX_FAIL(h, -2, "mcx_lsm_run: date %d coefficient offset out of range", d);
+    hipStream_t s = (hipStream_t)stream;
+    // workspace of the run: [moments NM | table n_dates*S*K | status n_dates]; freed on every exit path
+    double* d_ws = nullptr;
+    MCX_HIP(h, hipMalloc(&d_ws, sizeof(double) * NM + tab_bytes + st_bytes + 64));
+    double* d_mom = d_ws;
+    double* d_tab = d_ws + NM;
+    int32_t* d_st = (int32_t*)(d_tab + (size_t)n_dates * S * K);
+    int rc = 0;
+    for (int d = 0; d < n_dates && rc == 0; ++d) {
+        const mcx_lsm_date& q = h_dates[d];
+        rc = lsm_step_launch(h, b, product, q.roll_begin, q.roll_end, q.num_atom, q.x_atom, q.shift, q.scale, d_paths, n_paths, ld, d_W, ld_w,
+                             d_mom, flags, s, "mcx_lsm_run");
+        if (rc != 0) break;
+        if (h->comm && h->comm_ranks > 1) { rc = mcx_allreduce_f64(h, d_mom, NM, stream); if (rc != 0) break; }   // stream-ordered
+        K3Solve sv;
+        sv.shift = q.shift; sv.scale = q.scale; sv.x0 = q.x0; sv.off0 = q.coeff_off[0]; sv.off1 = q.coeff_off[1];
+        sv.degenerate = q.degenerate; sv.K = K; sv.S = S; sv.date = d;
+        hipLaunchKernelGGL(k3_solve, dim3(1), dim3(64), 0, s, d_mom, sv, b->d_coeffs, d_tab, d_st);
+        if (hipGetLastError() != hipSuccess) { h->err = "mcx_lsm_run: launch failed"; rc = -100; }
+    }
+    if (rc == 0 && (hipMemcpyAsync(h_coeffs, d_tab, tab_bytes, hipMemcpyDeviceToHost, s) != hipSuccess ||
+                    hipMemcpyAsync(h_status, d_st, st_bytes, hipMemcpyDeviceToHost, s) != hipSuccess)) { h->err = "mcx_lsm_run: copy failed"; rc = -100; }
+    if (hipStreamSynchronize(s) != hipSuccess && rc == 0) { h->err = "mcx_lsm_run: synchronise failed"; rc = -100; }
+    hipFree(d_ws);
+    return rc;
 }
 
 extern "C" int mcx_lsm_step_batch(mcx_handle* h, const mcx_book* b, const mcx_lsm_job* h_jobs, int32_t n_jobs, int32_t n_states,

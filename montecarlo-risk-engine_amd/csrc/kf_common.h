@@ -35,7 +35,9 @@ struct ChunkHeader { int32_t n_ev, n_mop, n_terms, bytes; };
 // optional threshold / EPE-ENE record / CVA increment).  Such a date runs ~130 instructions of branch-light code with every
 // control field in SGPRs instead of ~500 instructions of event interpretation; any other date uses the interpreter.
 struct FastDate {
-    int32_t valid, flags;            // flags: 1 cash, 2 expo, 4 cva, 8 profile, 16 constant numeraire, 32 metric op present,
+    int32_t valid, flags;            // valid: 0 interpreted, 1 straight-line in every fused kernel, 2 straight-line in kf_lean only
+                                     // (exercise event / state-dependent exposure: flags 128 / 256)
+                                     // flags: 1 cash, 2 expo, 4 cva, 8 profile, 16 constant numeraire, 32 metric op present,
                                      // 64: the CVA increment may use the merged discount x survival factor (m_*): no threshold,
                                      //     no EPE / ENE record on this date
     int32_t ni_reg, lin_reg, n_exp, x_reg, coeff_off0, coeff_off1, rec_profile, s_reg, c_reg, pad;
@@ -48,11 +50,19 @@ struct FastDate {
     double s_b, s_c0, s_c1;          // S(0,t)       = s_b exp(s_c0 + s_c1 reg[s_reg])
     double c_a, c_b, c_c0, c_c1;     // S(t,t+) cond = c_a + c_b exp(c_c0 + c_c1 reg[c_reg])
     double m_b, m_c0, m_n1, m_s1;    // S(0,t) / numeraire = m_b exp(m_c0 + m_n1 reg[ni_reg] + m_s1 reg[s_reg])   (flag 64)
+    // flag 128: exercise event of the book's ONE two-state exercise product (bermudan_option.py:93-131): immediate value
+    // max(ex_sign (ex_k0 + ex_k1 reg[ex_lin_reg] + sum_j w_j exp(c0_j + c1_j reg[r_j]) - ex_strike), 0) over the LeanTerm range
+    // [ex_term_off, ex_term_off + ex_n); continuation = polynomial (row of state 1 at ex_coeff_off + n_basis) in ex_x_a + ex_x_d reg[ex_x_reg]
+    // flag 256: the exposure polynomial's coefficient row is indexed by the lane's exercise state (coeff_off0 + state * n_basis)
+    int32_t ex_n, ex_term_off, ex_coeff_off, ex_x_reg, ex_lin_reg, ex_pad;
+    double ex_k0, ex_k1, ex_strike, ex_sign, ex_x_a, ex_x_d;
 };
+struct LeanTerm { double w, c0, c1; int32_t reg, pad; };     // w exp(c0 + c1 reg[reg]), read through scalar loads
 
 struct FusedArgs {
     K1Args k1;
     const FastDate* __restrict__ fast;        // [n_dates]
+    const LeanTerm* __restrict__ lterms;      // exponential terms of the exercise values (FastDate::ex_term_off)
     const unsigned char* __restrict__ prog;   // per-date program chunks (header | events | terms | metric ops)
     const int32_t* __restrict__ date_off;     // [n_dates+1] byte offset of each date's chunk (16-byte aligned)
     const int32_t* __restrict__ date_row;     // [n_dates] exposure row of this timeline date or -1

@@ -26,7 +26,7 @@ __device__ __forceinline__ bool kf_fast_date(const FusedArgs& a, int t, int64_t 
 {
     constexpr int NREG = 2 * NSLOT;
     if (NNS != 1) return false;
-    if (!ALL_FAST && ldk(&a.fast[t].valid) == 0) return false;
+    if (!ALL_FAST && ldk(&a.fast[t].valid) != 1) return false;
     const FastDate* __restrict__ fp = a.fast + t;                // every field is a scalar load at its point of use
 #define FD(x) ldk(&fp->x)
     const K1Args& k = a.k1;
@@ -426,6 +426,8 @@ struct mcx_fused {
     int32_t* d_date_off;
     int32_t* d_date_row;
     int chunk_cap, npf;
+    int lean;                  // every date has a FastDate record kf_lean.hip can run (valid != 0)
+    LeanTerm* d_lterms;
     int32_t rec_pv[MCX_FUSED_MAX_NS], rec_cva[MCX_FUSED_MAX_NS];
     double lgd[MCX_FUSED_MAX_NS];
     int32_t init_state[MCX_FUSED_MAX_STATEFUL];
@@ -437,7 +439,7 @@ struct mcx_fused {
 extern "C" void mcx_fused_destroy(mcx_fused* f)
 {
     if (!f) return;
-    hipFree(f->d_prog); hipFree(f->d_fast); hipFree(f->d_date_off); hipFree(f->d_date_row); hipFree(f->d_partials); hipFree(f->d_out);
+    hipFree(f->d_lterms); hipFree(f->d_prog); hipFree(f->d_fast); hipFree(f->d_date_off); hipFree(f->d_date_row); hipFree(f->d_partials); hipFree(f->d_out);
     delete f;
 }
 
@@ -497,7 +499,7 @@ extern "C" int mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_boo
             FEvent fe;
             memset(&fe, 0, sizeof(fe));
             fe.kind = e.kind; fe.flags = e.flags; fe.coeff_off = e.coeff_off; fe.row = e.row; fe.ns = pr.netting_set; fe.sidx = sidx;
-            fe.init_state = pr.init_state; fe.strike = e.strike; fe.sign = e.sign;
+            fe.init_state = pr.init_state; fe.pad = pr.n_states; fe.strike = e.strike; fe.sign = e.sign;
             for (int w = 0; w < 4; ++w) fe.aux[w] = e.aux[w];
             if (e.kind == MCX_EV_OPTION && (e.aux[0] == 4.0 || e.aux[0] == 5.0)) { ok = false; why = "barrier monitoring is evaluated by the book kernel (K2)"; }
             fe.num = fatom(devatom_to_mcx(e.num), t);
@@ -560,6 +562,7 @@ extern "C" int mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_boo
 
     // straight-line records for dates of the linear-book shape (FastDate); such dates need no interpreted chunk
     std::vector<FastDate> fast(T);
+    std::vector<LeanTerm> lterms;
     const bool fast_dates_enabled = d->n_netting_sets == 1;
     for (int t = 0; t < T; ++t) {
         FastDate fd;
@@ -567,14 +570,37 @@ extern "C" int mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_boo
         fd.ni_reg = fd.lin_reg = fd.x_reg = fd.s_reg = fd.c_reg = -1;
         fd.coeff_off0 = fd.coeff_off1 = -1; fd.rec_profile = -1;
         for (int j = 0; j < 4; ++j) fd.t_reg[j] = -1;
-        bool okf = fast_dates_enabled;
+        bool okf = fast_dates_enabled, lean_only = false;
         const FAtom* num = nullptr;
         int n_expo = 0;
         for (const FEvent& e : by_date[t]) {
             if (!okf) break;
-            if (e.sidx >= 0 || (e.kind != MCX_EV_CASHFLOW && e.kind != MCX_EV_EXPO_POLY)) { okf = false; break; }
+            const bool stateful = e.sidx >= 0;
+            if (stateful && (e.sidx != 0 || e.pad != 2 || d->n_netting_sets != 1)) { okf = false; break; }      // one two-state product
+            if (e.kind != MCX_EV_CASHFLOW && e.kind != MCX_EV_EXPO_POLY && !(e.kind == MCX_EV_EXERCISE && stateful && e.aux[0] == 0.0)) { okf = false; break; }
+            if (stateful && e.kind == MCX_EV_CASHFLOW) { okf = false; break; }
             if (num && memcmp(num, &e.num, sizeof(FAtom)) != 0) { okf = false; break; }     // one numeraire per date
             num = &e.num;
+            if (e.kind == MCX_EV_EXERCISE) {
+                if ((fd.flags & (128 | 2)) || e.x.b != 0.0) { okf = false; break; }            // one exercise event, before the exposure
+                fd.flags |= 128; lean_only = true;
+                fd.ex_term_off = (int32_t)lterms.size(); fd.ex_coeff_off = e.coeff_off; fd.ex_strike = e.strike; fd.ex_sign = e.sign;
+                fd.ex_x_reg = e.x.reg; fd.ex_x_a = e.x.a; fd.ex_x_d = e.x.d; fd.ex_lin_reg = -1;
+                for (int j = e.term_begin; j < e.term_end && okf; ++j) {
+                    const FTerm& tm = terms_by_date[t][j];
+                    fd.ex_k0 += tm.w * tm.atom.a;
+                    if (tm.atom.d != 0.0) {
+                        if (fd.ex_lin_reg >= 0 && fd.ex_lin_reg != tm.atom.reg) okf = false;
+                        fd.ex_lin_reg = tm.atom.reg; fd.ex_k1 += tm.w * tm.atom.d;
+                    }
+                    if (tm.atom.b != 0.0) {
+                        if (tm.atom.reg < 0 || tm.atom.c1 == 0.0) fd.ex_k0 += tm.w * tm.atom.b * exp(tm.atom.c0);      // state-independent term
+                        else { LeanTerm lt; lt.w = tm.w * tm.atom.b; lt.c0 = tm.atom.c0; lt.c1 = tm.atom.c1; lt.reg = tm.atom.reg; lt.pad = 0; lterms.push_back(lt); }
+                    }
+                }
+                fd.ex_n = (int32_t)lterms.size() - fd.ex_term_off;
+                continue;
+            }
             if (e.kind == MCX_EV_CASHFLOW) {
                 fd.flags |= 1;
                 for (int j = e.term_begin; j < e.term_end && okf; ++j) {
@@ -593,8 +619,11 @@ extern "C" int mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_boo
             } else {
                 if (e.x.b != 0.0 || n_expo >= 2) { okf = false; break; }
                 if ((fd.flags & 2) && (fd.x_reg != e.x.reg || fd.x_a != e.x.a || fd.x_d != e.x.d)) { okf = false; break; }
+                if (stateful && n_expo > 0) { okf = false; break; }                            // the state-indexed exposure stands alone
+                if ((fd.flags & 256)) { okf = false; break; }
                 fd.flags |= 2; fd.x_reg = e.x.reg; fd.x_a = e.x.a; fd.x_d = e.x.d;
-                const int off = e.coeff_off >= 0 ? e.coeff_off + e.init_state * book->n_basis : -1;
+                int off = e.coeff_off >= 0 ? e.coeff_off + e.init_state * book->n_basis : -1;
+                if (stateful) { fd.flags |= 256; lean_only = true; off = e.coeff_off; if (off < 0) { okf = false; break; } }
                 (n_expo == 0 ? fd.coeff_off0 : fd.coeff_off1) = off;
                 n_expo++;
             }
@@ -621,6 +650,7 @@ extern "C" int mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_boo
         // lane's state registers without a range test
         auto bind = [](int32_t& r, double& coef) { if (r < 0) { r = 0; coef = 0.0; } };
         bind(fd.ni_reg, fd.ni_c1); bind(fd.lin_reg, fd.k1); bind(fd.x_reg, fd.x_d); bind(fd.s_reg, fd.s_c1); bind(fd.c_reg, fd.c_c1);
+        bind(fd.ex_x_reg, fd.ex_x_d); bind(fd.ex_lin_reg, fd.ex_k1);
         for (int j = 0; j < 4; ++j) bind(fd.t_reg[j], fd.t_c1[j]);
         // merged discount x survival factor of the CVA increment: relu(p / N) S (1 - Sc) = relu(p) (S / N) (1 - Sc) when the date
         // has no threshold and records no EPE / ENE profile: one exponential instead of two
@@ -630,7 +660,8 @@ extern "C" int mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_boo
             else { fd.m_b = fd.s_b; fd.m_c0 = fd.s_c0 + fd.ni_c0; fd.m_n1 = fd.ni_c1; }
             fd.m_s1 = fd.s_c1;
         }
-        fd.valid = okf ? 1 : 0;
+        if (!okf) lterms.resize(fd.ex_term_off <= (int32_t)lterms.size() && (fd.flags & 128) ? fd.ex_term_off : lterms.size());
+        fd.valid = okf ? (lean_only ? 2 : 1) : 0;
         fast[t] = fd;
     }
     // per-date program chunks: header | events | terms | metric ops, 16-byte aligned
@@ -641,7 +672,7 @@ extern "C" int mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_boo
     for (int t = 0; t < T; ++t) for (const FEvent& e : by_date[t]) if (e.kind == MCX_EV_EXPO_BS) bs_exposure = true;
     for (int t = 0; t < T; ++t) {
         date_off[t] = (int32_t)prog.size();
-        if (fast[t].valid) continue;                   // evaluated from its FastDate record: no interpreted chunk
+        if (fast[t].valid == 1) continue;              // evaluated from its FastDate record in every kernel: no interpreted chunk
         ChunkHeader hd;
         hd.n_ev = (int)by_date[t].size(); hd.n_mop = (int)mop_by_date[t].size(); hd.n_terms = (int)terms_by_date[t].size();
         const size_t bytes = sizeof(hd) + sizeof(FEvent) * by_date[t].size() + sizeof(FTerm) * terms_by_date[t].size() +
@@ -660,11 +691,12 @@ extern "C" int mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_boo
     date_off[T] = (int32_t)prog.size();
     if (bs_exposure) { delete f; MCX_FAIL(h, MCX_E_NOT_FUSABLE, "not fusable: analytic Black-Scholes exposures are evaluated by the book kernel (K2)"); }
     // LDS budget: 4 wave slots + the record area must fit comfortably (several blocks per CU)
-    bool all_fast = d->n_netting_sets == 1 && n_stateful == 0;
-    for (int t = 0; t < T; ++t) all_fast = all_fast && fast[t].valid;
+    bool all_fast = d->n_netting_sets == 1 && n_stateful == 0, lean = d->n_netting_sets == 1 && n_stateful <= 1;
+    for (int t = 0; t < T; ++t) { all_fast = all_fast && fast[t].valid == 1; lean = lean && fast[t].valid != 0; }
     f->npf = max_chunk <= 1024 ? 1 : (max_chunk <= 2048 ? 2 : 0);
     f->chunk_cap = f->npf > 0 ? f->npf * 1024 : ((max_chunk + 255) & ~255);
-    if (all_fast) { f->npf = -1; f->chunk_cap = 0; }      // no interpreted date at all: the straight-line instantiation
+    if (all_fast) { f->npf = -1; f->chunk_cap = 0; }      // no interpreted date at all: the straight-line instantiations
+    f->lean = lean ? 1 : 0;
     if ((size_t)4 * f->chunk_cap + sizeof(double) * 9 * (size_t)n_rec > 60 * 1024) {
         delete f;
         MCX_FAIL(h, MCX_E_NOT_FUSABLE, "not fusable: a date's event program (%d B) exceeds the per-wave LDS slot budget", max_chunk);
@@ -681,6 +713,8 @@ extern "C" int mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_boo
     prog.resize(prog.size() + 4096, 0);       // slack so the fixed-size prefetch of the last chunk stays in bounds
     MCX_HIP(h, up((void**)&f->d_prog, prog.data(), prog.size()));
     MCX_HIP(h, up((void**)&f->d_fast, fast.data(), sizeof(FastDate) * fast.size()));
+    lterms.resize(lterms.size() + 1);          // never empty
+    MCX_HIP(h, up((void**)&f->d_lterms, lterms.data(), sizeof(LeanTerm) * lterms.size()));
     MCX_HIP(h, up((void**)&f->d_date_off, date_off.data(), sizeof(int32_t) * date_off.size()));
     MCX_HIP(h, up((void**)&f->d_date_row, date_row.data(), sizeof(int32_t) * date_row.size()));
     f->partial_bytes = sizeof(double) * 4 * (size_t)n_rec * 2048;
@@ -710,7 +744,7 @@ static int fused_run_impl(mcx_handle* h, const mcx_fused* f, bool simulate, uint
     FusedArgs a;
     memset(&a, 0, sizeof(a));
     mcx_fill_k1_args(f->sim, seed, path_offset, n_paths, ld > 0 ? ld : n_paths, d_paths, d_inject_z, d_inject_u, &a.k1);
-    a.prog = f->d_prog; a.fast = f->d_fast; a.date_off = f->d_date_off; a.chunk_cap = f->chunk_cap;
+    a.prog = f->d_prog; a.fast = f->d_fast; a.lterms = f->d_lterms; a.date_off = f->d_date_off; a.chunk_cap = f->chunk_cap;
     a.date_row = f->d_date_row; a.coeffs = f->book->d_coeffs; a.cfs = d_cfs; a.expo = d_expo; a.partials = f->d_partials;
     a.ld_out = ld_out; a.n_dates = f->n_dates; a.n_basis = f->book->n_basis; a.n_ns = f->n_ns; a.n_rec = f->n_rec;
     a.n_expo_rows = f->n_expo_rows; a.n_stateful = f->n_stateful;
@@ -719,7 +753,7 @@ static int fused_run_impl(mcx_handle* h, const mcx_fused* f, bool simulate, uint
     hipStream_t s = (hipStream_t)stream;
     const bool inj = d_inject_z != nullptr;
     int grid;
-    if (simulate && f->npf < 0) {
+    if (simulate && f->lean) {
         // every date is a straight-line record: the two-paths-per-lane kernel of kf_lean.hip
         grid = mcx_launch_kf_lean(a, sd, h->n_cu, inj, s);
         if (grid < 0) MCX_FAIL(h, MCX_E_NOT_FUSABLE, "not fusable: (slots=%d, z=%d) has no fused instantiation", sd.n_slots, sd.n_z);
@@ -761,7 +795,7 @@ static int fused_run_impl(mcx_handle* h, const mcx_fused* f, bool simulate, uint
 
 extern "C" int mcx_fused_is_straight_line(const mcx_fused* f)
 {
-    return (f && f->npf < 0) ? 1 : 0;
+    return (f && f->lean) ? 1 : 0;
 }
 
 extern "C" int mcx_fused_run(mcx_handle* h, const mcx_fused* f, uint64_t seed, uint64_t path_offset, int64_t n_paths,

@@ -86,7 +86,8 @@ __device__ __forceinline__ void lean_record(const double (&v)[PPL], const bool (
 
 template <int NSLOT, int SIG, int PPL>
 __device__ __forceinline__ void lean_date(int t, const int64_t (&i)[PPL], const bool (&live)[PPL], bool first_tile,
-                                          double* __restrict__ lds, const double (&reg)[PPL][2 * NSLOT], double (&cfs)[PPL], double (&cva)[PPL])
+                                          double* __restrict__ lds, const double (&reg)[PPL][2 * NSLOT], double (&cfs)[PPL], double (&cva)[PPL],
+                                          int (&est)[PPL])
 {
     // (state registers are indexed by wave-uniform record fields: M0-relative VGPR reads; mcx_fused_create binds an absent
     // reference to register 0 with a zero coefficient, so no range test is needed)
@@ -103,7 +104,7 @@ __device__ __forceinline__ void lean_date(int t, const int64_t (&i)[PPL], const 
     // cashflows feed the PV record / the cashflow output only; a CVA / exposure-profile run skips them
     const bool want_cash = (flags & 1) && (a.cfs != nullptr || a.rec_pv[0] >= 0);
     // CVA-only date without threshold: relu(p / N) S (1 - Sc) = relu(p) (S / N) (1 - Sc), one exponential for S / N
-    const bool merged = (flags & 64) && !want_cash && a.expo == nullptr;
+    const bool merged = (flags & 64) && !(flags & 128) && !want_cash && a.expo == nullptr;
     double inv[PPL];
     if (!merged) {
         if (flags & 16) {
@@ -133,6 +134,37 @@ __device__ __forceinline__ void lean_date(int t, const int64_t (&i)[PPL], const 
 #pragma unroll
         for (int q = 0; q < PPL; ++q) cfs[q] = fma(val[q], inv[q], cfs[q]);
     }
+    if (flags & 128) {
+        // exercise event of the two-state product (bermudan_option.py:93-131): exercise iff the immediate value exceeds the
+        // regression continuation value and a right is left; the (up to ~64) exponential terms of the immediate value come
+        // through scalar loads, one 32-byte record per term, and serve both paths of the lane
+        const double k0 = FD(ex_k0), k1 = FD(ex_k1), strike = FD(ex_strike), sign = FD(ex_sign);
+        const int lr = FD(ex_lin_reg), n_t = FD(ex_n);
+        const LeanTerm* __restrict__ lt = a.lterms + FD(ex_term_off);
+        double val[PPL];
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) val[q] = fma(k1, reg[q][lr], k0);
+#pragma unroll 1
+        for (int j = 0; j < n_t; ++j) {
+            const LeanTerm tm = ldk_struct(lt + j);
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) val[q] = fma(tm.w, mcx_exp(fma(tm.c1, reg[q][tm.reg], tm.c0), ec), val[q]);
+        }
+        const double xa = FD(ex_x_a), xd = FD(ex_x_d);
+        const int xr = FD(ex_x_reg), co = FD(ex_coeff_off);
+        double x[PPL], cont[PPL];
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) { x[q] = fma(xd, reg[q][xr], xa); cont[q] = 0.0; }
+        if (co >= 0) lean_poly_add<PPL>(a.coeffs + co + a.n_basis, a.n_basis, x, cont);      // row of state 1 (a right is left)
+        const bool want_ex_cash = a.cfs != nullptr || a.rec_pv[0] >= 0;
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) {
+            const double imm = fmax(sign * (val[q] - strike), 0.0);
+            const bool ex = (imm > cont[q]) && (est[q] > 0);
+            if (want_ex_cash) cfs[q] = ex ? fma(imm, inv[q], cfs[q]) : cfs[q];
+            est[q] = ex ? est[q] - 1 : est[q];
+        }
+    }
     double p[PPL];
 #pragma unroll
     for (int q = 0; q < PPL; ++q) p[q] = 0.0;
@@ -142,8 +174,19 @@ __device__ __forceinline__ void lean_date(int t, const int64_t (&i)[PPL], const 
         double x[PPL];
 #pragma unroll
         for (int q = 0; q < PPL; ++q) x[q] = fma(xd, reg[q][xr], xa);
-        if (off0 >= 0) lean_poly_add<PPL>(a.coeffs + off0, a.n_basis, x, p);
-        if (off1 >= 0) lean_poly_add<PPL>(a.coeffs + off1, a.n_basis, x, p);
+        if (flags & 256) {
+            // exposure of the exercise product: the coefficient row of the lane's state (product.py:150-184)
+            double p0[PPL], p1[PPL];
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) { p0[q] = 0.0; p1[q] = 0.0; }
+            lean_poly_add<PPL>(a.coeffs + off0, a.n_basis, x, p0);
+            lean_poly_add<PPL>(a.coeffs + off0 + a.n_basis, a.n_basis, x, p1);
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) p[q] = est[q] > 0 ? p1[q] : p0[q];
+        } else {
+            if (off0 >= 0) lean_poly_add<PPL>(a.coeffs + off0, a.n_basis, x, p);
+            if (off1 >= 0) lean_poly_add<PPL>(a.coeffs + off1, a.n_basis, x, p);
+        }
     }
     // survival probability over the next interval, conditional on the credit state (cva_metric.py:66-89)
     auto cond_surv = [&](double (&cs)[PPL]) {
@@ -232,6 +275,7 @@ __global__ __launch_bounds__(MCX_BLOCK, MCX_LEAN_WAVES) void kf_lean(const Fused
         uint64_t path[PPL];
         double reg[PPL][NREG];                         // reg[q][2s], reg[q][2s+1] = state of slot s of the lane's q-th path
         double cfs[PPL], cva[PPL];
+        int est[PPL];                                  // rights left of the book's (at most one) exercise product
         int n_init, n_steps;
         {
             KArgs& a = kargs_region(mcx_region_zero());          // tile prologue
@@ -244,6 +288,7 @@ __global__ __launch_bounds__(MCX_BLOCK, MCX_LEAN_WAVES) void kf_lean(const Fused
                 path[q] = k.path_offset + (uint64_t)i[q];
                 sim_init_state<NSLOT, SIG>(k, reg[q]);
                 cfs[q] = 0.0; cva[q] = 0.0;
+                est[q] = a.init_state[0];
             }
             const int64_t rest = n - tile * TILE;
             n_block += (double)(rest < TILE ? rest : TILE);
@@ -271,7 +316,7 @@ __global__ __launch_bounds__(MCX_BLOCK, MCX_LEAN_WAVES) void kf_lean(const Fused
                     ++step;
                 }
             }
-            if (st >= 0) lean_date<NSLOT, SIG, PPL>(st, i, live, first_tile, lds, reg, cfs, cva);
+            if (st >= 0) lean_date<NSLOT, SIG, PPL>(st, i, live, first_tile, lds, reg, cfs, cva, est);
         }
         {
             KArgs& a = kargs_region(mcx_region_zero());          // tile epilogue: per-path quantities

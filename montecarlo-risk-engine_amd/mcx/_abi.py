@@ -85,6 +85,10 @@ def ptr(a: np.ndarray | None) -> C.c_void_p:
 
 
 # mcx_lsm_job (include/mcx.h)
+LSM_DATE_DTYPE = np.dtype([("roll_begin", np.int32), ("roll_end", np.int32), ("num_atom", np.int32), ("x_atom", np.int32),
+                           ("degenerate", np.int32), ("reserved", np.int32), ("coeff_off", np.int64, (2,)),
+                           ("shift", np.float64), ("scale", np.float64), ("x0", np.float64)])
+assert LSM_DATE_DTYPE.itemsize == 64
 LSM_JOB_DTYPE = np.dtype([("product", np.int32), ("roll_begin", np.int32), ("roll_end", np.int32), ("num_atom", np.int32),
                           ("x_atom", np.int32), ("reserved", np.int32), ("w_offset", np.int64), ("shift", np.float64),
                           ("scale", np.float64)], align=True)

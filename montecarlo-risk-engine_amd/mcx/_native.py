@@ -22,7 +22,7 @@ _EXPORTS = [
     "mcx_sim_create", "mcx_sim_destroy", "mcx_generate_paths", "mcx_generate_paths_from_state", "mcx_rng_draws",
     "mcx_comm_unique_id", "mcx_comm_init", "mcx_comm_destroy", "mcx_allreduce_f64", "mcx_allgather_f64",
     "mcx_book_create", "mcx_book_destroy", "mcx_book_set_coeffs", "mcx_eval_book", "mcx_resolve_atoms",
-    "mcx_lsm_stats", "mcx_lsm_step", "mcx_lsm_step_batch", "mcx_book_set_coeffs_batch", "mcx_book_set_bridge_rng",
+    "mcx_lsm_stats", "mcx_lsm_step", "mcx_lsm_run", "mcx_lsm_step_batch", "mcx_book_set_coeffs_batch", "mcx_book_set_bridge_rng",
     "mcx_fused_is_straight_line", "mcx_tangent_paths", "mcx_tangent_lsm", "mcx_tangent_eval", "mcx_tangent_cva", "mcx_tangent_profiles", "mcx_tangent_pick",
     "mcx_tangent_european", "mcx_fused_create", "mcx_fused_destroy", "mcx_fused_num_records", "mcx_fused_run", "mcx_fused_eval_paths", "mcx_fused_run_device", "mcx_fused_eval_paths_device",
     "mcx_reduce_vector", "mcx_reduce_profiles", "mcx_reduce_cva", "mcx_unsecured", "mcx_select_hist",
@@ -178,6 +178,10 @@ class HipBackend:
         out = C.c_void_p()
         self._check(self.lib.mcx_book_create(self.h, C.byref(plan.desc), C.byref(out)), "mcx_book_create")
         return _Owned(out, self.lib.mcx_book_destroy, plan)
+
+    def book_reset_coeffs(self, book, values: np.ndarray):
+        """the coefficient array as it was uploaded at book_create (a re-run of a cached book starts from the same state)"""
+        self.book_set_coeffs(book, 0, values)
 
     def book_set_coeffs(self, book, offset: int, values: np.ndarray):
         v = np.ascontiguousarray(values, dtype=np.float64).reshape(-1)
@@ -380,6 +384,19 @@ class HipBackend:
             _vp(W.data_ptr()), C.c_int64(W.shape[1]), _vp(moments.data_ptr()), C.c_int32(int(flags)), self._stream()),
             "mcx_lsm_step")
         return moments
+
+    def lsm_run(self, book, product: int, dates: np.ndarray, paths: torch.Tensor, W: torch.Tensor, flags: int = 0):
+        """the backward induction of one product without host round trips (mcx_lsm_run): dates = LSM_DATE_DTYPE array in
+        induction order -> (coefficients [n_dates][S][K], status [n_dates])"""
+        dates = np.ascontiguousarray(dates, dtype=_abi.LSM_DATE_DTYPE)
+        n, K, S = paths.shape[2], book.plan.n_basis, W.shape[0]
+        coeffs = np.zeros((len(dates), S, K))
+        status = np.zeros(len(dates), dtype=np.int32)
+        self._check(self.lib.mcx_lsm_run(
+            self.h, book.ptr, C.c_int32(product), _abi.ptr(dates), C.c_int32(len(dates)), _vp(paths.data_ptr()), C.c_int64(n),
+            C.c_int64(n), _vp(W.data_ptr()), C.c_int64(W.shape[1]), _abi.ptr(coeffs), _abi.ptr(status), C.c_int32(int(flags)),
+            self._stream()), "mcx_lsm_run")
+        return coeffs, status
 
     def lsm_step_batch(self, book, jobs: np.ndarray, n_states: int, paths: torch.Tensor, W: torch.Tensor, ld_w: int,
                        flags: int = 0) -> np.ndarray:

@@ -401,6 +401,9 @@ class SimulationController:
         for p_i, p, sched, atoms in jobs:
             S = p.get_num_states()
             W = be.zeros(S, n_local)
+            if hasattr(be, "lsm_run") and shard.world == 1 and self._lsm_on_device(be, p_i, p, sched, atoms, x_range, paths, W, S, K, lsm_flags):
+                continue
+            W.zero_()
             for (t_reg, r0, r1, prod_idx, expo_idx), (num, x) in zip(sched, atoms):
                 xmin, xmax = x_range[x]
                 degenerate = not (xmax > xmin)
@@ -415,6 +418,31 @@ class SimulationController:
                 if expo_idx is not None:
                     self.regression_coeffs[p_i][expo_idx] = torch.from_numpy(coeffs)
                     be.book_set_coeffs(self.book, self._expo_coeff_base[p_i] + expo_idx * S * K, coeffs)
+
+    def _lsm_on_device(self, be, p_i, p, sched, atoms, x_range, paths, W, S, K, lsm_flags) -> bool:
+        """the product's whole backward induction enqueued on the device (mcx_lsm_run): roll, moments, K x K solve and coefficient
+        scatter of every date back to back, one synchronisation at the end.  False when a system came out numerically singular
+        (the caller then runs the per-date loop with the host solver, which falls back to lstsq)."""
+        dates = np.zeros(len(sched), dtype=_abi.LSM_DATE_DTYPE)
+        for j, ((t_reg, r0, r1, prod_idx, expo_idx), (num, x)) in enumerate(zip(sched, atoms)):
+            xmin, xmax = x_range[x]
+            degenerate = not (xmax > xmin)
+            d = dates[j]
+            d["roll_begin"], d["roll_end"], d["num_atom"], d["x_atom"], d["degenerate"] = r0, r1, num, x, int(degenerate)
+            d["shift"] = 0.5 * (xmin + xmax) if not degenerate else xmin
+            d["scale"] = 2.0 / (xmax - xmin) if not degenerate else 1.0
+            d["x0"] = xmin
+            d["coeff_off"][0] = -1 if prod_idx is None else self._reg_coeff_base[p_i] + prod_idx * S * K
+            d["coeff_off"][1] = -1 if expo_idx is None else self._expo_coeff_base[p_i] + expo_idx * S * K
+        coeffs, status = be.lsm_run(self.book, p_i, dates, paths, W, flags=lsm_flags)
+        if status.any():
+            return False
+        for j, (t_reg, r0, r1, prod_idx, expo_idx) in enumerate(sched):
+            if prod_idx is not None:
+                p.regression_coeffs[prod_idx] = torch.from_numpy(coeffs[j].copy())
+            if expo_idx is not None:
+                self.regression_coeffs[p_i][expo_idx] = torch.from_numpy(coeffs[j].copy())
+        return True
 
     def _perform_regression_batched(self, shard: Shard, jobs, x_range, paths, n_local: int, K: int, lsm_flags: int):
         """The backward LSM induction of ALL products at once: step r of every product's schedule runs in one launch per
@@ -775,13 +803,26 @@ class SimulationController:
                     len(self.netting_sets), len(self.products), t1 - t0, t2 - t1, 0.0, t4 - t2, t4 - t0)
         return self._package(results, [], [])
 
+    def _compile_key(self):
+        """everything the compiled descriptors depend on besides the (immutable) object graph of this controller: the model
+        parameter VALUES (bumped runs change them), the smoothing flag and the backend"""
+        return (tuple(float(p.detach()) for p in self.model.get_model_params()), bool(self.model.perform_smoothing), id(self.backend))
+
     def _compile_all(self):
-        """objects -> descriptors, LSM atoms registered before the plan is frozen and uploaded"""
+        """objects -> descriptors, LSM atoms registered before the plan is frozen and uploaded.  A controller that is run again
+        with unchanged model parameters reuses the descriptors and the uploaded book of its previous run (the host-side
+        compilation of a 120-date Bermudan swaption is ~25 ms of Python against ~35 ms of GPU work)."""
+        key = self._compile_key()
+        if getattr(self, "_compiled_key", None) == key and getattr(self, "book", None) is not None:
+            self.backend.book_reset_coeffs(self.book, self._coeffs_at_upload)
+            return
         self._compile()
         if self.requires_regression:
             self._register_regression_atoms()
         self.book_plan = BookPlan(self._comp, *self._plan_args)
         self.book = self.backend.book_create(self.book_plan)
+        self._coeffs_at_upload = self.book_plan.coeffs.copy()
+        self._compiled_key = key
 
     def _evaluate_all(self, shard, cfs, expo, paths, fused_records=None):
         analytical = [[0.0 for _ in self.risk_metrics.metrics] for _ in self.netting_sets]

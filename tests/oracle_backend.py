@@ -87,6 +87,9 @@ class OracleBackend:
     def book_create(self, plan):
         return _Obj(plan)
 
+    def book_reset_coeffs(self, book, values):
+        self.book_set_coeffs(book, 0, values)
+
     def book_set_coeffs(self, book, offset, values):
         v = np.ascontiguousarray(values, dtype=np.float64).reshape(-1)
         book.plan.coeffs[offset:offset + v.size] = v

@@ -50,3 +50,21 @@ def test_ragged_path_counts_gpu_vs_oracle(n, fused, hip, oracle):
         assert np.allclose(a[:, 0], b[:, 0], rtol=1e-9, atol=1e-12, equal_nan=True), (n, a, b)
         if n > 1:
             assert np.allclose(a[:, 1], b[:, 1], rtol=1e-6, atol=1e-12, equal_nan=True), (n, a, b)
+
+
+def test_rerun_reuses_the_compiled_book_and_recompiles_after_a_parameter_change(oracle):
+    """a second run_simulation() of the same controller skips the host compilation (descriptor cache keyed on the model
+    parameter values) and reproduces the first run bit for bit; changing a parameter recompiles"""
+    import torch
+    sc, _ = cases.make_controller("bermudan_swaption", oracle)
+    r1 = sc.run_simulation()
+    book1 = sc.book
+    r2 = sc.run_simulation()
+    assert sc.book is book1
+    for a, b in zip(r1.results[0], r2.results[0]):
+        assert np.array_equal(np.array(a), np.array(b))
+    with torch.no_grad():
+        sc.model.get_model_params()[1].mul_(1.1)          # volatility
+    r3 = sc.run_simulation()
+    assert sc.book is not book1
+    assert not np.allclose(np.array(r3.results[0][0])[:, 0], np.array(r1.results[0][0])[:, 0], rtol=1e-9)
