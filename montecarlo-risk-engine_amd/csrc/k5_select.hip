@@ -32,30 +32,54 @@ __global__ __launch_bounds__(MCX_BLOCK) void k5_hist(const DevUnsec u, const dou
     for (int j = 0; j < K5_MAX_SEL; ++j) pf.p[j] = j < n_sel ? prefix[m * n_sel + j] : 0;
     __syncthreads();
     const int hi = shift + bits;
-    for (int64_t i = (int64_t)blockIdx.x * MCX_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * MCX_BLOCK) {
-        const uint64_t k = dev_key(dev_unsec(u, expo, ld, m, i));
-        const uint32_t digit = (uint32_t)((k >> shift) & (uint64_t)(nb - 1));
-        for (int j = 0; j < n_sel; ++j) {
-            const bool match = hi >= 64 || (k >> hi) == (pf.p[j] >> hi);
-            // Exposures of one date share their leading bits, so in the high-order passes most lanes of a wave hit the SAME
-            // bin: aggregate per distinct digit with ballots (one LDS atomic per distinct digit per wave) instead of 64
-            // serialised same-address atomics.
-            unsigned long long todo = __ballot(match);
-            const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63;
+    // four elements per lane and iteration: the four loads are in flight together (one 8-byte load per lane and iteration left
+    // the pass latency-bound at ~1.4 TB/s)
+    constexpr int UN = 4;
+    const int64_t stride = (int64_t)gridDim.x * MCX_BLOCK;
+    for (int64_t i0 = (int64_t)blockIdx.x * MCX_BLOCK + threadIdx.x; i0 < n; i0 += UN * stride) {
+        uint64_t kk[UN];
+        bool in[UN];
+#pragma unroll
+        for (int w = 0; w < UN; ++w) {
+            const int64_t i = i0 + w * stride;
+            in[w] = i < n;
+            kk[w] = dev_key(dev_unsec(u, expo, ld, m, in[w] ? i : n - 1));
+        }
+#pragma unroll
+        for (int w = 0; w < UN; ++w) {
+            const uint64_t k = kk[w];
+            const uint32_t digit = (uint32_t)((k >> shift) & (uint64_t)(nb - 1));
+#pragma unroll                                      // (compile-time j: a run-time index would put the prefixes into scratch memory)
+            for (int j = 0; j < K5_MAX_SEL; ++j) {
+                if (j >= n_sel) break;
+                // neighbouring ranks (q-1, q, q+1) share their prefix until the very last digits: count such a selection once
+                if (j > 0 && (hi >= 64 || (pf.p[j] >> hi) == (pf.p[0] >> hi))) continue;
+                const bool match = in[w] && (hi >= 64 || (k >> hi) == (pf.p[j] >> hi));
+                // Exposures of one date share their leading bits, so in the high-order passes most lanes of a wave hit the SAME
+                // bin: aggregate per distinct digit with ballots (one LDS atomic per distinct digit per wave) instead of 64
+                // serialised same-address atomics.
+                unsigned long long todo = __ballot(match);
 #pragma unroll 1
-            for (int round = 0; round < 2 && todo; ++round) {          // the (at most two) dominant digits of the wave
-                const int leader = __ffsll((long long)todo) - 1;
-                const uint32_t d = (uint32_t)__shfl((int)digit, leader, MCX_WAVE);
-                const unsigned long long same = __ballot(match && digit == d) & todo;
-                if (lane == leader) atomicAdd(&lh[j * nb + d], (uint32_t)__popcll(same));
-                todo &= ~same;
+                for (int round = 0; round < 2 && todo; ++round) {          // the (at most two) dominant digits of the wave
+                    const int leader = __ffsll((long long)todo) - 1;
+                    const uint32_t d = (uint32_t)__shfl((int)digit, leader, MCX_WAVE);
+                    const unsigned long long same = __ballot(match && digit == d) & todo;
+                    if (lane == leader) atomicAdd(&lh[j * nb + d], (uint32_t)__popcll(same));
+                    todo &= ~same;
+                }
+                if ((todo >> lane) & 1ull) atomicAdd(&lh[j * nb + digit], 1u);   // scattered remainder: distinct bins, no conflict
             }
-            if ((todo >> lane) & 1ull) atomicAdd(&lh[j * nb + digit], 1u);   // scattered remainder: distinct bins, no conflict
         }
     }
     __syncthreads();
     for (int q = threadIdx.x; q < n_sel * nb; q += MCX_BLOCK) {
-        const uint32_t c = lh[q];
+        const int j = q / nb;
+        uint64_t pj = pf.p[0];
+#pragma unroll
+        for (int w = 1; w < K5_MAX_SEL; ++w) pj = (j == w) ? pf.p[w] : pj;
+        const bool shared = j > 0 && (hi >= 64 || (pj >> hi) == (pf.p[0] >> hi));
+        const uint32_t c = lh[shared ? q - j * nb : q];
         if (c) atomicAdd(&hist[(int64_t)m * n_sel * nb + q], (unsigned long long)c);
     }
 }
@@ -75,16 +99,14 @@ extern "C" int mcx_select_hist(mcx_handle* h, const mcx_unsecured_desc* u, const
     DevUnsec du; int32_t* tmp = nullptr;
     int rc = mcx_upload_unsec(h, u, &du, &tmp, s);
     if (rc) return rc;
-    uint64_t* d_prefix = nullptr;
-    MCX_HIP(h, hipMalloc(&d_prefix, sizeof(uint64_t) * (size_t)u->n_dates * n_sel));
-    MCX_HIP(h, hipMemcpyAsync(d_prefix, h_prefix, sizeof(uint64_t) * (size_t)u->n_dates * n_sel, hipMemcpyHostToDevice, s));
-    MCX_HIP(h, hipStreamSynchronize(s));
-    int gx = mcx_grid_for(n_paths, MCX_BLOCK * 8, 4 * h->n_cu / (u->n_dates > 4 ? 4 : u->n_dates) + 1);
+    const uint64_t* d_prefix = (const uint64_t*)mcx_stage_small(h, h_prefix, sizeof(uint64_t) * (size_t)u->n_dates * n_sel, s);
+    if (!d_prefix) return -100;
+    // a block pays a fixed cost (zeroing and scanning its n_sel x 2^bits LDS bins): give it >= 32 elements per thread, and no
+    // more blocks than ~16 per CU over all dates
+    int gx = mcx_grid_for(n_paths, MCX_BLOCK * 32, (16 * h->n_cu + u->n_dates - 1) / u->n_dates);
     const size_t lds = sizeof(uint32_t) * (size_t)n_sel * ((size_t)1 << bits);
     hipLaunchKernelGGL(k5_hist, dim3(gx, u->n_dates), dim3(MCX_BLOCK), lds, s, du, d_expo_ns, n_paths, ld, (int)n_sel, d_prefix,
                        (int)shift, (int)bits, (unsigned long long*)d_hist);
     MCX_HIP(h, hipGetLastError());
-    MCX_HIP(h, hipStreamSynchronize(s));
-    hipFree(d_prefix); hipFree(tmp);
-    return 0;
+    return 0;          // stream-ordered: the caller reads d_hist through the stream (a collective or a copy)
 }

@@ -20,6 +20,11 @@ extern "C" int mcx_create(mcx_handle** out, int device_id)
     h->comm = nullptr; h->comm_ranks = 1; h->comm_rank = 0;
     if (hipMalloc(&h->d_ws, h->ws_bytes) != hipSuccess) { delete h; return -5; }
     if (hipHostMalloc(&h->h_pinned, h->pinned_bytes, hipHostMallocDefault) != hipSuccess) { hipFree(h->d_ws); delete h; return -6; }
+    h->small_bytes = 1u << 20; h->small_cursor = 0; h->d_small = nullptr; h->h_small = nullptr;
+    if (hipMalloc((void**)&h->d_small, h->small_bytes) != hipSuccess ||
+        hipHostMalloc((void**)&h->h_small, h->small_bytes, hipHostMallocDefault) != hipSuccess) {
+        hipFree(h->d_small); hipFree(h->d_ws); hipHostFree(h->h_pinned); delete h; return -7;
+    }
     *out = h;
     return 0;
 }
@@ -30,6 +35,8 @@ extern "C" void mcx_destroy(mcx_handle* h)
     mcx_comm_destroy(h);
     hipFree(h->d_ws);
     hipHostFree(h->h_pinned);
+    hipFree(h->d_small);
+    hipHostFree(h->h_small);
     delete h;
 }
 
@@ -223,17 +230,35 @@ extern "C" int mcx_book_set_bridge_rng(mcx_handle* h, mcx_book* b, uint64_t seed
 }
 
 // ---- shared helpers ---------------------------------------------------------------------------------------------------
+void* mcx_stage_small(mcx_handle* h, const void* src, size_t bytes, hipStream_t s)
+{
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    if (need > h->small_bytes) { h->err = "descriptor too large for the staging ring"; return nullptr; }
+    if (h->small_cursor + need > h->small_bytes) {                  // wrap: everything staged so far must have been consumed
+        if (hipStreamSynchronize(s) != hipSuccess) { h->err = "hipStreamSynchronize failed"; return nullptr; }
+        h->small_cursor = 0;
+    }
+    unsigned char* hp = h->h_small + h->small_cursor;
+    unsigned char* dp = h->d_small + h->small_cursor;
+    memcpy(hp, src, bytes);
+    if (hipMemcpyAsync(dp, hp, bytes, hipMemcpyHostToDevice, s) != hipSuccess) { h->err = "hipMemcpyAsync failed"; return nullptr; }
+    h->small_cursor += need;
+    return dp;
+}
+
 int mcx_upload_unsec(mcx_handle* h, const mcx_unsecured_desc* u, DevUnsec* out, int32_t** d_tmp, hipStream_t s)
 {
     if (u->n_dates < 1 || u->n_dates > MCX_MAX_METRIC_DATES) MCX_FAIL(h, -2, "unsecured desc: n_dates %d out of range", u->n_dates);
-    int32_t* d = nullptr;
-    MCX_HIP(h, hipMalloc(&d, sizeof(int32_t) * 2 * (size_t)u->n_dates));
-    MCX_HIP(h, hipMemcpyAsync(d, u->row, sizeof(int32_t) * u->n_dates, hipMemcpyHostToDevice, s));
-    if (u->delayed) MCX_HIP(h, hipMemcpyAsync(d + u->n_dates, u->delayed, sizeof(int32_t) * u->n_dates, hipMemcpyHostToDevice, s));
-    MCX_HIP(h, hipStreamSynchronize(s));     // host arrays may be transient
+    *d_tmp = nullptr;                                               // (nothing to free: the tables live in the staging ring)
+    const int32_t* d_row = (const int32_t*)mcx_stage_small(h, u->row, sizeof(int32_t) * u->n_dates, s);
+    if (!d_row) return -100;
+    const int32_t* d_del = nullptr;
+    if (u->delayed) {
+        d_del = (const int32_t*)mcx_stage_small(h, u->delayed, sizeof(int32_t) * u->n_dates, s);
+        if (!d_del) return -100;
+    }
     out->n_dates = u->n_dates; out->collateralized = u->collateralized; out->threshold = u->threshold;
-    out->row = d; out->delayed = u->delayed ? d + u->n_dates : nullptr;
-    *d_tmp = d;
+    out->row = d_row; out->delayed = d_del;
     return 0;
 }
 

@@ -25,6 +25,11 @@ struct mcx_handle {
     void* h_pinned;        // pinned staging for small device->host results
     size_t pinned_bytes;
     hipDeviceProp_t prop;
+    // small-descriptor staging ring: host arrays of a call (row tables, prefixes, atom ids) travel pinned -> device without a
+    // hipMalloc / hipFree per call (mcx_stage_small)
+    unsigned char* d_small;
+    unsigned char* h_small;
+    size_t small_bytes, small_cursor;
     void* comm;            // ncclComm_t of mcx_comm_init (mcx_comm.hip) or nullptr
     int comm_ranks, comm_rank;
 };
@@ -233,6 +238,9 @@ __device__ __forceinline__ double dev_barrier_ind(int type, double b, double mx,
 }
 
 // host-side helpers implemented in mcx_api.hip
+// copy `bytes` of host data to device memory that stays valid for the kernels enqueued on `s` by the current API call (a ring:
+// wrapping synchronises the stream first); returns nullptr and sets the handle's error on failure
+void* mcx_stage_small(mcx_handle* h, const void* src, size_t bytes, hipStream_t s);
 int mcx_upload_unsec(mcx_handle* h, const mcx_unsecured_desc* u, DevUnsec* out, int32_t** d_tmp, hipStream_t s);
 int mcx_finish_acc(mcx_handle* h, const double* d_partials, int n_records, int n_blocks, double n_paths,
                    const double* d_shifts, mcx_acc* h_out, hipStream_t s);

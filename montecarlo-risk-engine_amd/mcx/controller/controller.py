@@ -701,6 +701,16 @@ class SimulationController:
             return None
         return self.backend.fused_create(self._sim, self.book, plan)
 
+    def _buffer(self, name: str, *shape):
+        """device buffer owned by the controller and reused by every later pass of the same shape (a 2 M-path exposure matrix is
+        2 GB: re-allocating it per run leaves the caching allocator to split and re-grow its segments, tens of ms per run)"""
+        bufs = self.__dict__.setdefault("_buffers", {})
+        t = bufs.get(name)
+        if t is None or tuple(t.shape) != tuple(shape):
+            bufs[name] = None
+            t = bufs[name] = self.backend.empty(*shape)
+        return t
+
     def _fused_pass(self, paths_out=None):
         be, f, eng = self.backend, self._fused, self._main_engine
         n = eng.num_paths
@@ -709,11 +719,11 @@ class SimulationController:
             plan = "fused" if (hasattr(be, "fused_is_straight_line") and be.fused_is_straight_line(f)) else "semi"
         semi = plan == "semi" and hasattr(be, "fused_eval_paths")
         need_expo = self._fused_needs_expo or self.materialize
-        paths = (paths_out if paths_out is not None else be.empty(self.sim_plan.n_dates, self.sim_plan.n_state, n)) \
+        paths = (paths_out if paths_out is not None else self._buffer("paths", self.sim_plan.n_dates, self.sim_plan.n_state, n)) \
             if (self.materialize or paths_out is not None or semi) else None
         bp = self.book_plan
-        expo = be.empty(bp.n_netting_sets, bp.n_expo_rows, n) if (need_expo and bp.desc.want_expo) else None
-        cfs = be.empty(bp.n_netting_sets, n) if (self.materialize and bp.desc.want_cfs) else None
+        expo = self._buffer("expo", bp.n_netting_sets, bp.n_expo_rows, n) if (need_expo and bp.desc.want_expo) else None
+        cfs = self._buffer("cfs", bp.n_netting_sets, n) if (self.materialize and bp.desc.want_cfs) else None
         # several GPUs: the records stay on the device until the ranks' records are gathered (one collective, one copy)
         kw = dict(device_records=True) if self._shard.device_collectives else {}
         if semi:
