@@ -137,5 +137,6 @@ __device__ __forceinline__ double f_regsel(int r, const double (&reg)[NREG])    
 
 
 // kf_lean.hip: launches the straight-line one-launch kernel for a book whose every date has a FastDate record; returns the
-// grid size (= number of per-block partial records written to a.partials), or -1 when (slots, z) has no instantiation
-int mcx_launch_kf_lean(const FusedArgs& a, const mcx_sim_desc& sd, int n_cu, bool inject, hipStream_t s);
+// grid size (= number of per-block partial records written to a.partials), or -1 when (slots, z) has no instantiation;
+// simulate = false: the date programs run on the paths tensor a.k1.paths (the evaluation pass of mcx_fused_eval_paths)
+int mcx_launch_kf_lean(const FusedArgs& a, const mcx_sim_desc& sd, int n_cu, bool inject, bool simulate, hipStream_t s);

@@ -348,15 +348,6 @@ __global__ __launch_bounds__(MCX_BLOCK) void kf_fused(const FusedArgs a)
     kf_body<NSLOT, NZ, INJECT, SIG, NNS, NST, NPF, SIMULATE>(a);
 }
 
-// the straight-line instantiation (every date has a FastDate record).  Forcing it to <= 64 VGPRs (8 waves/SIMD, which would
-// make 2^20 paths = 16 wave-tiles per SIMD exactly two rounds) was measured SLOWER (1.82 vs 1.61 ms): the allocator's own
-// choice (67 VGPRs, 7 waves) stays.
-template <int NSLOT, int NZ, bool INJECT, int SIG, bool SIMULATE>
-__global__ __launch_bounds__(MCX_BLOCK) void kf_fused_lean(const FusedArgs a)
-{
-    kf_body<NSLOT, NZ, INJECT, SIG, 1, 0, -1, SIMULATE>(a);
-}
-
 // merge per-block records (Chan, Golub, LeVeque pairwise update) -> out[r] = (n, mean, 0, M2).
 // One 256-thread block per record: every thread folds a strided subset of the block records (independent loads in
 // flight), the 256 partial triples are then combined through LDS.  (A one-thread serial merge over 2048 dependent loads
@@ -400,8 +391,7 @@ void launch_kf(const FusedArgs& a, int grid, size_t lds, int npf, bool inject, b
     const bool one_ns = a.n_ns == 1, no_state = a.n_stateful == 0;
 #define MCX_KF(INJ, NNS, NST, NPF) do { if (simulate) hipLaunchKernelGGL((kf_fused<NSLOT, NZ, INJ, SIG, NNS, NST, NPF, true>), dim3(grid), dim3(MCX_BLOCK), lds, s, a); \
         else if (!INJ) hipLaunchKernelGGL((kf_fused<NSLOT, NZ, false, SIG, NNS, NST, NPF, false>), dim3(grid), dim3(MCX_BLOCK), lds, s, a); } while (0)
-#define MCX_KF_LEAN(INJ) do { if (!simulate && !INJ) hipLaunchKernelGGL((kf_fused_lean<NSLOT, NZ, false, SIG, false>), dim3(grid), dim3(MCX_BLOCK), lds, s, a); } while (0)
-#define MCX_KF_NPF(INJ, NNS, NST) do { if (npf < 0 && NNS == 1 && NST == 0) MCX_KF_LEAN(INJ); else if (npf == 1) MCX_KF(INJ, NNS, NST, 1); else if (npf == 2) MCX_KF(INJ, NNS, NST, 2); else MCX_KF(INJ, NNS, NST, 0); } while (0)
+#define MCX_KF_NPF(INJ, NNS, NST) do { if (npf == 1) MCX_KF(INJ, NNS, NST, 1); else if (npf == 2) MCX_KF(INJ, NNS, NST, 2); else MCX_KF(INJ, NNS, NST, 0); } while (0)
     if (inject) {
         if (one_ns && no_state) MCX_KF_NPF(true, 1, 0);
         else MCX_KF(true, MCX_FUSED_MAX_NS, MCX_FUSED_MAX_STATEFUL, 0);
@@ -411,7 +401,6 @@ void launch_kf(const FusedArgs& a, int grid, size_t lds, int npf, bool inject, b
         else MCX_KF(false, MCX_FUSED_MAX_NS, MCX_FUSED_MAX_STATEFUL, 0);
     }
 #undef MCX_KF_NPF
-#undef MCX_KF_LEAN
 #undef MCX_KF
 }
 
@@ -753,9 +742,9 @@ static int fused_run_impl(mcx_handle* h, const mcx_fused* f, bool simulate, uint
     hipStream_t s = (hipStream_t)stream;
     const bool inj = d_inject_z != nullptr;
     int grid;
-    if (simulate && f->lean) {
-        // every date is a straight-line record: the two-paths-per-lane kernel of kf_lean.hip
-        grid = mcx_launch_kf_lean(a, sd, h->n_cu, inj, s);
+    if (f->lean && (simulate || !inj)) {
+        // every date is a straight-line record: the two-paths-per-lane kernel of kf_lean.hip (simulating, or streaming a paths tensor)
+        grid = mcx_launch_kf_lean(a, sd, h->n_cu, inj, simulate, s);
         if (grid < 0) MCX_FAIL(h, MCX_E_NOT_FUSABLE, "not fusable: (slots=%d, z=%d) has no fused instantiation", sd.n_slots, sd.n_z);
     } else {
         const int64_t tiles = (n_paths + MCX_BLOCK - 1) / MCX_BLOCK;

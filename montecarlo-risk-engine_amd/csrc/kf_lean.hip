@@ -84,7 +84,7 @@ __device__ __forceinline__ void lean_record(const double (&v)[PPL], const bool (
     }
 }
 
-template <int NSLOT, int SIG, int PPL>
+template <int NSLOT, int SIG, int PPL, bool STORE>
 __device__ __forceinline__ void lean_date(int t, const int64_t (&i)[PPL], const bool (&live)[PPL], bool first_tile,
                                           double* __restrict__ lds, const double (&reg)[PPL][2 * NSLOT], double (&cfs)[PPL], double (&cva)[PPL],
                                           int (&est)[PPL])
@@ -96,7 +96,7 @@ __device__ __forceinline__ void lean_date(int t, const int64_t (&i)[PPL], const 
     const FastDate* __restrict__ fp = a.fast + t;
     const auto& k = a.k1;
     const mcx_exp_coef ec = mcx_exp_load(zd);
-    if (k.paths) {
+    if (STORE && k.paths) {
 #pragma unroll
         for (int q = 0; q < PPL; ++q) if (live[q]) sim_store_state<NSLOT, SIG>(k, t, i[q], reg[q]);
     }
@@ -251,7 +251,9 @@ __device__ __forceinline__ void lean_date(int t, const int64_t (&i)[PPL], const 
 #define MCX_LEAN_PPL 2
 #define MCX_LEAN_WAVES 4
 #endif
-template <int NSLOT, int NZ, bool INJECT, int SIG, int PPL>
+// SIMULATE = false: the same date programs on a paths tensor produced earlier by K1 (k1.paths is then the INPUT
+// [date][state][path]): one streaming pass, the next date's state columns in flight while this date's program runs
+template <int NSLOT, int NZ, bool INJECT, int SIG, int PPL, bool SIMULATE>
 __global__ __launch_bounds__(MCX_BLOCK, MCX_LEAN_WAVES) void kf_lean(const FusedArgs)      // read through kargs_region(), never by name
 {
     constexpr int NREG = 2 * NSLOT;
@@ -261,9 +263,9 @@ __global__ __launch_bounds__(MCX_BLOCK, MCX_LEAN_WAVES) void kf_lean(const Fused
     const int n_rec = a0.n_rec;
     const int64_t n = a0.k1.n;
     for (int q = threadIdx.x; q < 9 * n_rec; q += MCX_BLOCK) lds[q] = 0.0;
-    __shared__ double bm_lds[INJECT ? 2 : MCX_BM_LDS_DOUBLES];      // Box-Muller lookup tables
+    __shared__ double bm_lds[(INJECT || !SIMULATE) ? 2 : MCX_BM_LDS_DOUBLES];      // Box-Muller lookup tables
     const double* tab = nullptr;
-    if (!INJECT) { mcx_bm_load(bm_lds); tab = bm_lds; }
+    if (!INJECT && SIMULATE) { mcx_bm_load(bm_lds); tab = bm_lds; }
     __syncthreads();
     const int64_t tiles = (n + TILE - 1) / TILE;
     double n_block = 0.0;
@@ -294,6 +296,7 @@ __global__ __launch_bounds__(MCX_BLOCK, MCX_LEAN_WAVES) void kf_lean(const Fused
             n_block += (double)(rest < TILE ? rest : TILE);
             n_init = k.n_initial_store; n_steps = k.n_steps;
         }
+        if (SIMULATE) {
         // ONE date call site: the dates that hold the initial state come first (their sub-step run is empty), then
         // alternately a run of sub-steps up to the next timeline date and that date's program
         int step = 0, t_init = 0;
@@ -316,7 +319,34 @@ __global__ __launch_bounds__(MCX_BLOCK, MCX_LEAN_WAVES) void kf_lean(const Fused
                     ++step;
                 }
             }
-            if (st >= 0) lean_date<NSLOT, SIG, PPL>(st, i, live, first_tile, lds, reg, cfs, cva, est);
+            if (st >= 0) lean_date<NSLOT, SIG, PPL, true>(st, i, live, first_tile, lds, reg, cfs, cva, est);
+        }
+        } else {
+            double nxt[PPL][NREG];
+            auto load_row = [&](int t, double (&dst)[PPL][NREG]) {
+                const auto& k = kargs_region(0).k1;
+                const int D = k.n_state;
+#pragma unroll
+                for (int q = 0; q < PPL; ++q)
+#pragma unroll
+                    for (int sl = 0; sl < NSLOT; ++sl) {
+                        const bool bs = sig_kind(SIG, sl) >= 0 ? sig_is_bs(SIG, sl) : (k.slots[sl].kind == MCX_MODEL_BS);
+                        const int c = k.slots[sl].state_off;
+                        dst[q][2 * sl] = k.paths[((int64_t)t * D + c) * k.ld + i[q]];
+                        dst[q][2 * sl + 1] = bs ? 0.0 : k.paths[((int64_t)t * D + c + 1) * k.ld + i[q]];
+                    }
+            };
+            const int n_dates = kargs_region(0).n_dates;
+            load_row(0, nxt);
+#pragma unroll 1
+            for (int t = 0; t < n_dates; ++t) {
+#pragma unroll
+                for (int q = 0; q < PPL; ++q)
+#pragma unroll
+                    for (int r = 0; r < NREG; ++r) reg[q][r] = nxt[q][r];
+                if (t + 1 < n_dates) load_row(t + 1, nxt);            // next date's state streams in while this date's program runs
+                lean_date<NSLOT, SIG, PPL, false>(t, i, live, first_tile, lds, reg, cfs, cva, est);
+            }
         }
         {
             KArgs& a = kargs_region(mcx_region_zero());          // tile epilogue: per-path quantities
@@ -344,7 +374,7 @@ __global__ __launch_bounds__(MCX_BLOCK, MCX_LEAN_WAVES) void kf_lean(const Fused
 #undef FD
 
 template <int NSLOT, int NZ, int SIG>
-void launch_lean(const FusedArgs& a, int n_cu, bool inject, hipStream_t s, int* grid_out)
+void launch_lean(const FusedArgs& a, int n_cu, bool inject, bool simulate, hipStream_t s, int* grid_out)
 {
     constexpr int PPL = MCX_LEAN_PPL;
     const int64_t tiles = (a.k1.n + MCX_BLOCK * PPL - 1) / (MCX_BLOCK * PPL);
@@ -355,8 +385,9 @@ void launch_lean(const FusedArgs& a, int n_cu, bool inject, hipStream_t s, int* 
         grid = (int)((tiles + per - 1) / per);
     }
     const size_t lds = sizeof(double) * (size_t)((9 * a.n_rec + 1) & ~1);
-    if (inject) hipLaunchKernelGGL((kf_lean<NSLOT, NZ, true, SIG, PPL>), dim3(grid), dim3(MCX_BLOCK), lds, s, a);
-    else hipLaunchKernelGGL((kf_lean<NSLOT, NZ, false, SIG, PPL>), dim3(grid), dim3(MCX_BLOCK), lds, s, a);
+    if (!simulate) hipLaunchKernelGGL((kf_lean<NSLOT, NZ, false, SIG, PPL, false>), dim3(grid), dim3(MCX_BLOCK), lds, s, a);
+    else if (inject) hipLaunchKernelGGL((kf_lean<NSLOT, NZ, true, SIG, PPL, true>), dim3(grid), dim3(MCX_BLOCK), lds, s, a);
+    else hipLaunchKernelGGL((kf_lean<NSLOT, NZ, false, SIG, PPL, true>), dim3(grid), dim3(MCX_BLOCK), lds, s, a);
     *grid_out = grid;
 }
 
@@ -364,26 +395,26 @@ void launch_lean(const FusedArgs& a, int n_cu, bool inject, hipStream_t s, int* 
 
 // host entry used by kf_fused.hip (fused_run_impl); returns the grid size (number of per-block partial records), or -1 when
 // the (slots, z) shape has no instantiation
-int mcx_launch_kf_lean(const FusedArgs& a, const mcx_sim_desc& sd, int n_cu, bool inject, hipStream_t s)
+int mcx_launch_kf_lean(const FusedArgs& a, const mcx_sim_desc& sd, int n_cu, bool inject, bool simulate, hipStream_t s)
 {
     int grid = -1;
     switch (mcx_sim_signature(sd)) {
-    case SIG_VAS_CIR_E: launch_lean<2, 2, SIG_VAS_CIR_E>(a, n_cu, inject, s, &grid); break;
+    case SIG_VAS_CIR_E: launch_lean<2, 2, SIG_VAS_CIR_E>(a, n_cu, inject, simulate, s, &grid); break;
 #ifndef MCX_LEAN_ONE_SIG
-    case SIG_BS_A: launch_lean<1, 1, SIG_BS_A>(a, n_cu, inject, s, &grid); break;
-    case SIG_BS_E: launch_lean<1, 1, SIG_BS_E>(a, n_cu, inject, s, &grid); break;
-    case SIG_HESTON_QE: launch_lean<1, 2, SIG_HESTON_QE>(a, n_cu, inject, s, &grid); break;
-    case SIG_HESTON_E: launch_lean<1, 2, SIG_HESTON_E>(a, n_cu, inject, s, &grid); break;
-    case SIG_VAS_E: launch_lean<1, 1, SIG_VAS_E>(a, n_cu, inject, s, &grid); break;
-    case SIG_VAS_A: launch_lean<1, 1, SIG_VAS_A>(a, n_cu, inject, s, &grid); break;
-    case SIG_BS_VAS_CIRDET_E: launch_lean<3, 3, SIG_BS_VAS_CIRDET_E>(a, n_cu, inject, s, &grid); break;
+    case SIG_BS_A: launch_lean<1, 1, SIG_BS_A>(a, n_cu, inject, simulate, s, &grid); break;
+    case SIG_BS_E: launch_lean<1, 1, SIG_BS_E>(a, n_cu, inject, simulate, s, &grid); break;
+    case SIG_HESTON_QE: launch_lean<1, 2, SIG_HESTON_QE>(a, n_cu, inject, simulate, s, &grid); break;
+    case SIG_HESTON_E: launch_lean<1, 2, SIG_HESTON_E>(a, n_cu, inject, simulate, s, &grid); break;
+    case SIG_VAS_E: launch_lean<1, 1, SIG_VAS_E>(a, n_cu, inject, simulate, s, &grid); break;
+    case SIG_VAS_A: launch_lean<1, 1, SIG_VAS_A>(a, n_cu, inject, simulate, s, &grid); break;
+    case SIG_BS_VAS_CIRDET_E: launch_lean<3, 3, SIG_BS_VAS_CIRDET_E>(a, n_cu, inject, simulate, s, &grid); break;
     default:
         switch (sd.n_slots * 16 + sd.n_z) {
-        case 1 * 16 + 1: launch_lean<1, 1, SIG_GENERIC>(a, n_cu, inject, s, &grid); break;
-        case 1 * 16 + 2: launch_lean<1, 2, SIG_GENERIC>(a, n_cu, inject, s, &grid); break;
-        case 2 * 16 + 2: launch_lean<2, 2, SIG_GENERIC>(a, n_cu, inject, s, &grid); break;
-        case 3 * 16 + 3: launch_lean<3, 3, SIG_GENERIC>(a, n_cu, inject, s, &grid); break;
-        case 4 * 16 + 4: launch_lean<4, 4, SIG_GENERIC>(a, n_cu, inject, s, &grid); break;
+        case 1 * 16 + 1: launch_lean<1, 1, SIG_GENERIC>(a, n_cu, inject, simulate, s, &grid); break;
+        case 1 * 16 + 2: launch_lean<1, 2, SIG_GENERIC>(a, n_cu, inject, simulate, s, &grid); break;
+        case 2 * 16 + 2: launch_lean<2, 2, SIG_GENERIC>(a, n_cu, inject, simulate, s, &grid); break;
+        case 3 * 16 + 3: launch_lean<3, 3, SIG_GENERIC>(a, n_cu, inject, simulate, s, &grid); break;
+        case 4 * 16 + 4: launch_lean<4, 4, SIG_GENERIC>(a, n_cu, inject, simulate, s, &grid); break;
         default: break;
         }
 #else
