@@ -429,6 +429,14 @@ int  mcx_lsm_step_batch(mcx_handle* h, const mcx_book* book, const mcx_lsm_job* 
 int  mcx_book_set_coeffs_batch(mcx_handle* h, mcx_book* book, const int64_t* h_offsets, int32_t n, int32_t len,
                                const double* h_values, void* stream);
 
+/* Exercise decisions of MCX_EV_EXERCISE events recorded (mode 1) or replayed (mode 2) by mcx_eval_book and mcx_lsm_step* / mcx_lsm_run
+ * (mode 0: off): d_bits [n_events][ld] bytes, one per (event of the book, path); bit k = the decision of the LSM roll that started
+ * in exercise state k (bit 0 in the main simulation).  The reference's tape carries no gradient through the boolean
+ * `should_exercise` (bermudan_option.py:122-128), i.e. its sensitivities hold the exercise policy fixed: bump-and-revalue runs of
+ * exercise products replay the base run's decisions so that no path flips its policy under the bump.  The fused kernels do not
+ * record or replay (callers run the K1 / K2 / K4 plan while a mode is set).  ld >= the paths of the next call. */
+int  mcx_book_set_exercise_replay(mcx_handle* h, mcx_book* book, int32_t mode, uint8_t* d_bits, int64_t ld);
+
 /* RNG of the Brownian-bridge barrier events (OPTION mode 5), set before mcx_eval_book / mcx_lsm_step*: one uniform per monitored
  * interval k and barrier b from Philox4x32-10 with key = seed and counter = (global path id = path_offset + i, k,
  * 0x80000000 | (2 * draw_id + b)).  The reference draws them from a numpy Generator on the host (barrier_option.py:52-53, 163,

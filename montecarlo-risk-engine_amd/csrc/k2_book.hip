@@ -29,6 +29,9 @@ struct K2Args {
     // ACCUMULATES into its own zero-initialised [n_ns][*][ld_out] image (cfs / expo then point at the chunk images)
     int32_t chunk_products, n_netting_sets;
     const DevBridge* __restrict__ bridge;       // RNG state of Brownian-bridge barrier events (device struct of the book)
+    uint8_t* __restrict__ ex_bits;              // exercise-decision record / replay (mcx_book_set_exercise_replay)
+    int64_t ex_ld;
+    int32_t ex_mode;
 };
 
 __device__ __forceinline__ double dev_poly(const double* __restrict__ c, int K, double x)
@@ -43,7 +46,8 @@ __device__ __forceinline__ double dev_norm_cdf(double x) { return 0.5 * (1.0 + e
 // normalised cashflow of one product-date event for a path in exercise state s (s may be decremented)
 __device__ __forceinline__ double dev_cash_event(const DevEvent& e, const DevTerm* __restrict__ terms, const DevAtom* __restrict__ atoms,
                                                  const double* __restrict__ coeffs, int K, const double* __restrict__ paths,
-                                                 int64_t D, int64_t ld, int64_t i, int& s, const DevBridge* __restrict__ bridge)
+                                                 int64_t D, int64_t ld, int64_t i, int& s, const DevBridge* __restrict__ bridge,
+                                                 int ex_mode = 0, uint8_t* __restrict__ ex_cell = nullptr)
 {
     const double num = dev_atom(e.num, paths, D, ld, i);
     double common = 0.0, own = 0.0, glog = 0.0;
@@ -83,7 +87,7 @@ __device__ __forceinline__ double dev_cash_event(const DevEvent& e, const DevTer
         cont = dev_poly(coeffs + e.coeff_off + s * K, K, x);
         if (e.aux[0] == 1.0 && s > 0) cont_ex = dev_poly(coeffs + e.coeff_off + (s - 1) * K, K, x);
     }
-    const bool ex = (imm + cont_ex > cont) && (s > 0);
+    const bool ex = dev_exercise_decision((imm + cont_ex > cont) && (s > 0), s, ex_mode, ex_cell, 0);
     if (ex) s -= 1;
     return ex ? imm / num : 0.0;
 }
@@ -118,7 +122,8 @@ __global__ __launch_bounds__(MCX_BLOCK) void k2_eval_book(const K2Args a)
         for (int q = pr.ev_begin; q < pr.ev_end; ++q) {
             const DevEvent e = ldk_struct(&a.events[q]);
             if (e.kind <= MCX_EV_EXERCISE) {
-                acc += dev_cash_event(e, a.terms, a.atoms, a.coeffs, K, a.paths, D, ld, i, s, a.bridge);
+                acc += dev_cash_event(e, a.terms, a.atoms, a.coeffs, K, a.paths, D, ld, i, s, a.bridge, a.ex_mode,
+                                      a.ex_mode ? a.ex_bits + (int64_t)q * a.ex_ld + i : nullptr);
             } else {
                 double v = 0.0;
                 if (e.kind == MCX_EV_EXPO_POLY) {
@@ -189,6 +194,8 @@ extern "C" int mcx_eval_book(mcx_handle* h, const mcx_book* b, const double* d_p
     a.n_products = b->n_products; a.n_basis = b->n_basis; a.n_state = b->n_state; a.n_expo_rows = b->n_expo_rows;
     a.want_cfs = b->want_cfs; a.want_expo = b->want_expo;
     a.chunk_products = 0; a.n_netting_sets = b->n_netting_sets; a.bridge = b->d_bridge;
+    a.ex_mode = b->ex_mode; a.ex_bits = b->d_ex_bits; a.ex_ld = b->ex_ld;
+    if (a.ex_mode && a.ex_ld < n_paths) MCX_FAIL(h, -2, "mcx_eval_book: exercise replay buffer narrower than the path count");
     const int grid = (int)((n_paths + MCX_BLOCK - 1) / MCX_BLOCK);
     // Few paths x many products (the reference's 5,000-product books run on ~1,000 paths): the path grid alone leaves the
     // chip empty (4 workgroups) while every lane walks ~10^6 events.  Split the PRODUCT list over blockIdx.y instead; each

@@ -29,6 +29,9 @@ struct K3Args {
     int64_t n, ld, ld_w;
     int32_t roll_begin, roll_end, n_basis, n_state, f32_cache;
     const DevBridge* __restrict__ bridge;
+    uint8_t* __restrict__ ex_bits;         // exercise-decision record / replay (mcx_book_set_exercise_replay)
+    int64_t ex_ld;
+    int32_t ex_mode, ev_base;              // ev_base: book index of events[0]
 };
 
 __device__ __forceinline__ double k3_poly(const double* __restrict__ c, int K, double x)
@@ -83,14 +86,15 @@ __device__ __forceinline__ double k3_cash_event(const DevEvent& e, const K3Args&
 }
 
 // exercise decision of one hypothetical state s (bermudan_option.py:93-131, flexicall.py:118-133 for aux[0] = 1)
-__device__ __forceinline__ double k3_exercise(const DevEvent& e, const K3Args& a, double imm, double num, double x, int& s)
+__device__ __forceinline__ double k3_exercise(const DevEvent& e, const K3Args& a, double imm, double num, double x, int& s,
+                                              uint8_t* __restrict__ cell, int bit)
 {
     double cont = 0.0, cont_ex = 0.0;
     if (e.coeff_off >= 0) {
         cont = k3_poly(a.coeffs + e.coeff_off + s * a.n_basis, a.n_basis, x);
         if (e.aux[0] == 1.0 && s > 0) cont_ex = k3_poly(a.coeffs + e.coeff_off + (s - 1) * a.n_basis, a.n_basis, x);
     }
-    const bool ex = (imm + cont_ex > cont) && (s > 0);
+    const bool ex = dev_exercise_decision((imm + cont_ex > cont) && (s > 0), s, a.ex_mode, cell, bit);
     if (ex) s -= 1;
     return ex ? imm / num : 0.0;
 }
@@ -113,9 +117,10 @@ __device__ __forceinline__ void k3_roll(const K3Args& a, int64_t i, double (&y)[
             bool exercise;
             double imm = 0.0, num = 1.0, x = 0.0;
             const double v = k3_cash_event(e, a, D, i, exercise, imm, num, x);
+            uint8_t* cell = a.ex_mode ? a.ex_bits + (int64_t)(a.ev_base + q) * a.ex_ld + i : nullptr;
 #pragma unroll
             for (int s0 = 0; s0 < S; ++s0) {
-                sv[s0] += exercise ? k3_exercise(e, a, imm, num, x, st[s0]) : v;
+                sv[s0] += exercise ? k3_exercise(e, a, imm, num, x, st[s0], cell, s0) : v;
                 if (a.f32_cache) sv[s0] = (double)(float)sv[s0];             // float32 cf_cache quirk (controller.py:312-330)
             }
         }
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(MCX_BLOCK) void k3_step_batch(K3Args a, const K3Job
 {
     constexpr int NM = (2 * K - 1) + S * K;
     const K3Job jb = ldk_struct(&jobs[blockIdx.y]);
-    a.events += jb.ev_off; a.roll_begin = jb.roll_begin; a.roll_end = jb.roll_end; a.W += jb.w_off;
+    a.events += jb.ev_off; a.ev_base = jb.ev_off; a.roll_begin = jb.roll_begin; a.roll_end = jb.roll_end; a.W += jb.w_off;
     a.shift = jb.shift; a.scale = jb.scale; a.num = jb.num; a.x = jb.x;
     double acc[NM];
 #pragma unroll
@@ -503,6 +508,8 @@ static int lsm_step_launch(mcx_handle* h, const mcx_book* b, int32_t product, in
     a.W = d_W; a.partials = h->d_ws; a.num = flat(num_atom); a.x = flat(x_atom); a.shift = shift; a.scale = scale;
     a.n = n_paths; a.ld = ld; a.ld_w = ld_w; a.roll_begin = roll_begin; a.roll_end = roll_end; a.n_basis = K; a.n_state = b->n_state;
     a.f32_cache = (flags & MCX_LSM_F32_CACHE) ? 1 : 0; a.bridge = b->d_bridge;
+    a.ex_mode = b->ex_mode; a.ex_bits = b->d_ex_bits; a.ex_ld = b->ex_ld; a.ev_base = pr.cf_begin;
+    if (a.ex_mode && a.ex_ld < n_paths) MCX_FAIL(h, -2, "%s: exercise replay buffer narrower than the path count", who);
     const bool mfma = (flags & MCX_LSM_MFMA) != 0;
     int rc = -1;
     switch (S) {
@@ -612,6 +619,7 @@ extern "C" int mcx_lsm_step_batch(mcx_handle* h, const mcx_book* b, const mcx_ls
     a.terms = b->d_terms; a.events = b->d_events; a.atoms = b->d_atoms; a.coeffs = b->d_coeffs; a.paths = d_paths;
     a.W = d_W; a.partials = d_part; a.n = n_paths; a.ld = ld; a.ld_w = ld_w; a.n_basis = K; a.n_state = b->n_state;
     a.f32_cache = (flags & MCX_LSM_F32_CACHE) ? 1 : 0; a.bridge = b->d_bridge;
+    a.ex_mode = b->ex_mode; a.ex_bits = b->d_ex_bits; a.ex_ld = b->ex_ld; a.ev_base = 0;
     int rc = 0;
     for (int j0 = 0; j0 < n_jobs && rc == 0; j0 += chunk) {
         const int nj = n_jobs - j0 < chunk ? n_jobs - j0 : chunk;

@@ -167,6 +167,7 @@ extern "C" int mcx_book_create(mcx_handle* h, const mcx_book_desc* d, mcx_book**
 
     b->d_atoms = nullptr; b->d_terms = nullptr; b->d_events = nullptr; b->d_products = nullptr; b->d_coeffs = nullptr;
     b->d_bridge = nullptr; b->d_bridge_inject = nullptr;
+    b->ex_mode = 0; b->d_ex_bits = nullptr; b->ex_ld = 0;
     MCX_HIP(h, hipMalloc(&b->d_atoms, sizeof(DevAtom) * atoms.size()));
     MCX_HIP(h, hipMalloc(&b->d_terms, sizeof(DevTerm) * terms.size()));
     MCX_HIP(h, hipMalloc(&b->d_events, sizeof(DevEvent) * events.size()));
@@ -226,6 +227,14 @@ extern "C" int mcx_book_set_bridge_rng(mcx_handle* h, mcx_book* b, uint64_t seed
         br.inject = b->d_bridge_inject;
     }
     MCX_HIP(h, hipMemcpy(b->d_bridge, &br, sizeof(br), hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int mcx_book_set_exercise_replay(mcx_handle* h, mcx_book* b, int32_t mode, uint8_t* d_bits, int64_t ld)
+{
+    if (!h || !b) return -1;
+    if (mode < 0 || mode > 2 || (mode != 0 && (!d_bits || ld <= 0))) MCX_FAIL(h, -2, "mcx_book_set_exercise_replay: bad arguments");
+    b->ex_mode = mode; b->d_ex_bits = mode ? d_bits : nullptr; b->ex_ld = mode ? ld : 0;
     return 0;
 }
 

@@ -93,6 +93,10 @@ struct mcx_book {
     std::vector<int32_t> h_event_t_idx;
     std::vector<int32_t> h_event_num_atom, h_event_x_atom, h_term_atom;
     std::vector<DevProduct> h_products;
+    // exercise decisions recorded (1) / replayed (2) by K2 and K3 (mcx_book_set_exercise_replay): [n_events][ex_ld] bytes
+    int ex_mode;
+    uint8_t* d_ex_bits;
+    int64_t ex_ld;
     std::vector<uint8_t> ns_has_writer;   // [n_netting_sets * n_expo_rows]
     bool expo_needs_memset;
 };
@@ -157,6 +161,15 @@ __device__ __forceinline__ double dev_atom_cached(const DevAtom& a, const double
     double v = fma(a.d, x, a.a);
     if (a.b != 0.0) v = fma(a.b, mcx_exp(fma(a.c1, x, a.c0)), v);
     return v;
+}
+
+// exercise decision with optional record / replay (mcx_book_set_exercise_replay): `cell` = the (event, path) byte, `bit` = the
+// hypothetical start state of the LSM roll (0 in the main simulation)
+__device__ __forceinline__ bool dev_exercise_decision(bool decided, int s, int mode, uint8_t* __restrict__ cell, int bit)
+{
+    if (mode == 2) return ((*cell >> bit) & 1) && s > 0;
+    if (mode == 1) *cell = (uint8_t)((*cell & ~(1u << bit)) | ((unsigned)decided << bit));
+    return decided;
 }
 
 __device__ __forceinline__ double wave_sum(double v)

@@ -22,7 +22,7 @@ _EXPORTS = [
     "mcx_sim_create", "mcx_sim_destroy", "mcx_generate_paths", "mcx_generate_paths_from_state", "mcx_rng_draws",
     "mcx_comm_unique_id", "mcx_comm_init", "mcx_comm_destroy", "mcx_allreduce_f64", "mcx_allgather_f64",
     "mcx_book_create", "mcx_book_destroy", "mcx_book_set_coeffs", "mcx_eval_book", "mcx_resolve_atoms",
-    "mcx_lsm_stats", "mcx_lsm_step", "mcx_lsm_run", "mcx_lsm_step_batch", "mcx_book_set_coeffs_batch", "mcx_book_set_bridge_rng",
+    "mcx_lsm_stats", "mcx_lsm_step", "mcx_lsm_run", "mcx_lsm_step_batch", "mcx_book_set_coeffs_batch", "mcx_book_set_bridge_rng", "mcx_book_set_exercise_replay",
     "mcx_fused_is_straight_line", "mcx_tangent_paths", "mcx_tangent_lsm", "mcx_tangent_eval", "mcx_tangent_cva", "mcx_tangent_profiles", "mcx_tangent_pick",
     "mcx_tangent_european", "mcx_fused_create", "mcx_fused_destroy", "mcx_fused_num_records", "mcx_fused_run", "mcx_fused_eval_paths", "mcx_fused_run_device", "mcx_fused_eval_paths_device",
     "mcx_reduce_vector", "mcx_reduce_profiles", "mcx_reduce_cva", "mcx_unsecured", "mcx_select_hist",
@@ -178,6 +178,17 @@ class HipBackend:
         out = C.c_void_p()
         self._check(self.lib.mcx_book_create(self.h, C.byref(plan.desc), C.byref(out)), "mcx_book_create")
         return _Owned(out, self.lib.mcx_book_destroy, plan)
+
+    def book_set_exercise_replay(self, book, mode: int, bits: torch.Tensor | None):
+        """mode 0 off / 1 record / 2 replay the exercise decisions in `bits` (uint8 [n_events][n_paths]) by K2 and K3"""
+        if mode:
+            assert bits.dtype == torch.uint8 and bits.is_cuda and bits.is_contiguous() and bits.shape[0] == len(book.plan.events)
+        self._check(self.lib.mcx_book_set_exercise_replay(self.h, book.ptr, C.c_int32(mode), _vp(bits.data_ptr() if mode else 0),
+                                                          C.c_int64(bits.shape[1] if mode else 0)), "mcx_book_set_exercise_replay")
+        self._keep_replay = bits
+
+    def new_exercise_bits(self, n_events: int, n_paths: int) -> torch.Tensor:
+        return torch.zeros((n_events, n_paths), dtype=torch.uint8, device=self.device)
 
     def book_reset_coeffs(self, book, values: np.ndarray):
         """the coefficient array as it was uploaded at book_create (a re-run of a cached book starts from the same state)"""

@@ -18,7 +18,13 @@ COMMON RANDOM NUMBERS: the Philox counters (or the injected draws) are identical
 quotient converges to the same pathwise derivative the reference's tape returns (including the dependence of the regression
 coefficients on the parameters through the pre-simulation), with O(h^2) truncation and no sampling noise.  It costs 2P + 1
 passes of the millisecond-scale hot path and serves what the forward-mode kernels do not cover (exercise products, PFE,
-collateral, analytic exposures, non-Euler schemes)."""
+collateral, analytic exposures, non-Euler schemes).
+
+Exercise products (American / Bermudan / FlexiCall): the reference's tape has NO gradient through the boolean
+`should_exercise` (bermudan_option.py:122-128): its sensitivities hold the exercise policy fixed.  A plain bump would let paths
+near the exercise boundary flip their decision and add jump / (2 h N) spikes, so the base run RECORDS every exercise decision
+(pre-simulation roll and main simulation, mcx_book_set_exercise_replay) and the bumped pair REPLAYS them; pinned against the
+reference's autograd gradients (tests/golden/bermudan_swaption_aad.npz, american_put_aad.npz)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -137,7 +143,16 @@ def run_with_bumps(sc):
     t0 = time.perf_counter()
     smoothing = getattr(sc.model, "perform_smoothing", False)      # the reference differentiates the smoothed payoffs
     base = _clone_controller(sc, sc.model, sc.reference_float32_cf_cache)
+    # Exercise products: the reference's tape has no gradient through the boolean `should_exercise` (bermudan_option.py:122-128),
+    # i.e. its sensitivities hold the exercise policy fixed.  The base run records every exercise decision (pre-simulation roll
+    # and main simulation), the bumped runs replay them: no path flips its policy under the bump.
+    replay = None
+    if any(p.get_num_states() > 1 for p in sc.products) and hasattr(sc.backend, "book_set_exercise_replay"):
+        replay = dict(mode=1, pre=None, main=None)
+        base.exercise_replay = replay
     res0 = base.run_simulation()
+    if replay is not None:
+        base.backend.book_set_exercise_replay(base.book, 0, None)
     sc.sim_plan, sc.last_state = base.sim_plan, base.last_state
     theta = [float(p.detach()) for p in sc.model.get_model_params()]
     P = len(theta)
@@ -153,7 +168,12 @@ def run_with_bumps(sc):
             _set_param(m, j, theta[j] + sgn * h)
             # the float32 cashflow cache of the reference's LSM is a rounding artefact: differencing through it would only add
             # noise of size eps_f32 / h, so the bumped pair runs with the float64 cache
-            pair.append(_clone_controller(sc, m, False).run_simulation().results)
+            bumped = _clone_controller(sc, m, False)
+            if replay is not None:
+                bumped.exercise_replay = dict(mode=2, pre=replay["pre"], main=replay["main"])
+            pair.append(bumped.run_simulation().results)
+            if replay is not None:
+                bumped.backend.book_set_exercise_replay(bumped.book, 0, None)
         vals.append((pair, h))
     grads = []
     for ns_i, per_metric in enumerate(res0.results):

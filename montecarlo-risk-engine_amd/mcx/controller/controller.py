@@ -376,6 +376,7 @@ class SimulationController:
         paths = eng.generate_paths_native()
         self.last_state["paths_pre"] = paths
         self._set_bridge_rng(eng.seed, off, "bridge_pre")
+        self._set_exercise_replay("pre", n_local)
         K = self.regression_function.get_degree()
         comp = self._comp
         jobs = []
@@ -523,6 +524,18 @@ class SimulationController:
         if any(getattr(p, "use_brownian_bridge", False) for p in self.products):
             self.backend.book_set_bridge_rng(self.book, int(seed), int(path_offset), self._inject.get(inject_key))
 
+    def _set_exercise_replay(self, phase: str, n_paths: int):
+        """exercise decisions of this phase ("pre" / "main") recorded into, or replayed from, `self.exercise_replay`
+        (mcx/aad.py run_with_bumps: the bumped runs of an exercise product keep the base run's exercise policy, as the
+        reference's tape does — bermudan_option.py:122-128 puts no gradient through `should_exercise`)"""
+        rp = getattr(self, "exercise_replay", None)
+        if not rp:
+            return
+        be = self.backend
+        if rp["mode"] == 1 and rp.get(phase) is None:
+            rp[phase] = be.new_exercise_bits(len(self.book_plan.events), n_paths)
+        be.book_set_exercise_replay(self.book, rp["mode"], rp[phase])
+
     def _register_regression_atoms(self):
         """atoms the LSM needs must exist before the book is uploaded"""
         for p_i, p in enumerate(self.products):
@@ -666,7 +679,10 @@ class SimulationController:
                                              plan=self.sim_plan, sim=self._sim, seed_offset=self.seed_offset)
         if "main" in self._inject:
             self._main_engine.inject_z, self._main_engine.inject_u = self._inject["main"]
-        self._fused = self._build_fused() if (self.allow_fused and self._mc_products) else None
+        replaying = bool(getattr(self, "exercise_replay", None))
+        self._fused = self._build_fused() if (self.allow_fused and self._mc_products and not replaying) else None
+        if replaying:
+            self._set_exercise_replay("main", n_local)
         self._set_bridge_rng(self._main_engine.seed, self._main_engine.path_offset, "bridge_main")     # after the pre-simulation's
         be.synchronize()
 

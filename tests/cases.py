@@ -309,8 +309,12 @@ CASES = {
     # sensitivities through the LSM regression; the fixtures hold only the reference gradients, draws = the base case's
     "irs_cva_aad": (irs_cva, 1024, 1024, 2, E, True),
     "mixed_cva_aad": (mixed_cva, 512, 512, 2, E, True),
+    # exercise products: the reference's tape holds the exercise policy fixed (bermudan_option.py:122-128)
+    "bermudan_swaption_aad": (bermudan_swaption, 1024, 1024, 1, E, True),
+    "american_put_aad": (american, 2048, 1024, 1, A, True),
 }
-DRAWS_FROM = {"irs_cva_aad": "irs_cva", "mixed_cva_aad": "mixed_cva"}
+DRAWS_FROM = {"irs_cva_aad": "irs_cva", "mixed_cva_aad": "mixed_cva", "bermudan_swaption_aad": "bermudan_swaption",
+              "american_put_aad": "american_put"}
 
 
 def load_golden(name):

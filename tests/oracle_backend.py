@@ -87,6 +87,13 @@ class OracleBackend:
     def book_create(self, plan):
         return _Obj(plan)
 
+    def book_set_exercise_replay(self, book, mode, bits):
+        self.lib.orc_set_exercise_replay(C.c_int(mode), _p(bits) if mode else None, C.c_int64(bits.shape[1] if mode else 0))
+        self._keep_replay = bits
+
+    def new_exercise_bits(self, n_events, n_paths):
+        return torch.zeros((n_events, n_paths), dtype=torch.uint8)
+
     def book_reset_coeffs(self, book, values):
         self.book_set_coeffs(book, 0, values)
 
