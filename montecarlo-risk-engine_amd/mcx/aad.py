@@ -464,3 +464,52 @@ def run_analytic_with_autograd(sc):
         hess.append([[tuple(H)] if H is not None else [] for _ in sc.risk_metrics.metrics])
     sc.timings = dict(total=time.perf_counter() - t0, analytic=True)
     return sc._package(results, grads, hess if sc.requires_higher_order_derivatives else [])
+
+
+# ---- second-order derivatives of Monte-Carlo metrics (controller.py:253-255, 631-648) --------------------------------------------
+def run_second_order(sc):
+    """`compute_higher_derivatives()` with Monte-Carlo metrics: the Hessian as central differences, with common random numbers, of
+    the first-order sensitivities this module produces (forward-mode kernels where they exist, replayed bumps otherwise):
+    H[i][j] = (g_i(theta + h e_j) - g_i(theta - h e_j)) / 2h, 2P first-order runs.
+
+    What it estimates: the derivative of the pathwise gradient INCLUDING the paths that cross a payoff kink under the bump — the
+    term that makes a Monte-Carlo gamma non-zero.  The reference differentiates its tape a second time (`torch.autograd.grad` of
+    the gradient, controller.py:631-648), which sees d/dx 1[x > 0] = 0 and therefore returns only the smooth part (a
+    Black-Scholes call has gamma exactly 0 on its tape); for parameters that enter smoothly the two agree.  The reference's own
+    tests request second derivatives of analytically valued PVs only (tests/pytests/test_european_option_hessian.py), served by
+    `run_analytic_with_autograd`.  Bump: 1 % of the parameter (the kink term's variance grows like 1 / (N h))."""
+    import copy
+    from .controller.controller import SimulationController
+    t0 = time.perf_counter()
+    theta = [float(p.detach()) for p in sc.model.get_model_params()]
+    P = len(theta)
+
+    def first_order(model):
+        c = SimulationController(copy.deepcopy(sc.netting_sets), model, copy.deepcopy(sc.risk_metrics), sc.num_paths_mainsim,
+                                 sc.num_paths_presim, sc.num_steps, sc.simulation_scheme, differentiate=True,
+                                 regression_function=sc.regression_function, backend=sc.backend, use_mfma=sc.use_mfma)
+        for attr in ("seed_offset", "allow_fused", "main_plan", "materialize", "_inject", "forward_mode"):
+            setattr(c, attr, getattr(sc, attr))
+        return c, c.run_simulation()
+
+    base, res0 = first_order(sc.model)
+    sc.sim_plan, sc.last_state = base.sim_plan, base.last_state
+    cols = []                                       # cols[j][ns][metric][eval] = tuple over i of d g_i / d theta_j
+    for j in range(P):
+        h = 1e-2 * max(abs(theta[j]), 1e-2)
+        g = []
+        for sgn in (+1.0, -1.0):
+            m = copy.deepcopy(sc.model)
+            m.perform_smoothing = getattr(sc.model, "perform_smoothing", False)
+            for leaf in _leaf_models(m):
+                leaf.perform_smoothing = m.perform_smoothing
+            _set_param(m, j, theta[j] + sgn * h)
+            g.append(first_order(m)[1].derivatives)
+        cols.append([[[tuple((float(a) - float(b)) / (2.0 * h) for a, b in zip(ep, em)) for ep, em in zip(mp, mm)]
+                      for mp, mm in zip(np_, nm_)] for np_, nm_ in zip(g[0], g[1])])
+    higher = [[[tuple(tuple(cols[j][ns_i][m_i][e_i][i] for j in range(P)) for i in range(P))
+                for e_i in range(len(res0.derivatives[ns_i][m_i]))]
+               for m_i in range(len(res0.derivatives[ns_i]))] for ns_i in range(len(res0.derivatives))]
+    sc.timings = dict(total=time.perf_counter() - t0, second_order_by_differences=True, first_order_runs=2 * P + 1)
+    return sc._package([[[tuple(v) for v in evals] for evals in per_metric] for per_metric in res0.results],
+                       [[[tuple(ev) for ev in per_metric] for per_metric in per_ns] for per_ns in res0.derivatives], higher)

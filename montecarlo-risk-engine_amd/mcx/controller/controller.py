@@ -787,6 +787,9 @@ class SimulationController:
                                run_with_tangent_book, run_with_tangents, tangent_kernels_apply)
             if analytic_controller(self):
                 return run_analytic_with_autograd(self)             # PVMetric(ANALYTICAL): autograd on the closed form
+            if self.requires_higher_order_derivatives:
+                from ..aad import run_second_order
+                return run_second_order(self)                       # Monte-Carlo metrics: differences of the first-order pass
             if tangent_kernels_apply(self):
                 return run_with_tangents(self)
             if self.forward_mode and hasattr(self.backend, "tangent_paths"):

@@ -68,3 +68,24 @@ def test_rerun_reuses_the_compiled_book_and_recompiles_after_a_parameter_change(
     r3 = sc.run_simulation()
     assert sc.book is not book1
     assert not np.allclose(np.array(r3.results[0][0])[:, 0], np.array(r1.results[0][0])[:, 0], rtol=1e-9)
+
+
+def test_monte_carlo_second_order_derivatives_converge_to_the_black_scholes_hessian(oracle):
+    """compute_higher_derivatives() on a Monte-Carlo PV (controller.py:253-255, 631-648): differences of the pathwise first-order
+    sensitivities with common random numbers; 200 k paths against the closed-form gamma / vomma / vanna (Monte-Carlo noise ~2 %)"""
+    from scipy.stats import norm
+    ns, model, rm = cases.bs_european()
+    sc = SimulationController(ns, model, rm, 200000, 0, 2, cases.A, differentiate=True, backend=oracle)
+    sc.compute_higher_derivatives()
+    res = sc.run_simulation()
+    H = res.get_second_derivatives(0, "pv", evaluation_idx=0)
+    S, K, r, sig, T = 120.0, 100.0, 0.05, 0.2, 2.0
+    d1 = (math.log(S / K) + (r + 0.5 * sig * sig) * T) / (sig * math.sqrt(T))
+    d2 = d1 - sig * math.sqrt(T)
+    gamma = norm.pdf(d1) / (S * sig * math.sqrt(T))
+    vega = S * norm.pdf(d1) * math.sqrt(T)
+    assert abs(H["spot"]["spot"] - gamma) < 0.08 * gamma
+    assert abs(H["volatility"]["volatility"] - vega * d1 * d2 / sig) < 0.05 * abs(vega * d1 * d2 / sig)
+    assert abs(H["spot"]["volatility"] - (-norm.pdf(d1) * d2 / sig)) < 0.08 * abs(norm.pdf(d1) * d2 / sig)
+    assert abs(H["spot"]["volatility"] - H["volatility"]["spot"]) < 0.08 * abs(H["spot"]["volatility"])          # symmetric up to noise
+    assert res.get_derivatives(0, "pv", evaluation_idx=0)["spot"] == pytest.approx(0.875, abs=0.01)
