@@ -185,7 +185,7 @@ typedef struct {
     int32_t n_atoms, n_terms, n_events, n_products;
     int32_t n_netting_sets, n_expo_rows, n_basis, n_coeffs;
     int32_t want_cfs, want_expo;
-    int32_t n_state, reserved;   /* D of the paths tensor the atoms index into */
+    int32_t n_state, n_dates;    /* D and T of the paths tensor [T][D][ld] the atoms index into (every t_idx is checked against T) */
     const mcx_atom*    atoms;
     const mcx_term*    terms;
     const mcx_event*   events;

@@ -215,20 +215,16 @@ extern "C" int mcx_eval_book(mcx_handle* h, const mcx_book* b, const double* d_p
     n_chunks = (b->n_products + a.chunk_products - 1) / a.chunk_products;
     const int64_t n_cfs = b->want_cfs ? (int64_t)b->n_netting_sets * ld_out : 0;
     const int64_t n_expo = b->want_expo ? (int64_t)b->n_netting_sets * b->n_expo_rows * ld_out : 0;
-    double* d_part = nullptr;
-    MCX_HIP(h, hipMalloc(&d_part, sizeof(double) * (size_t)n_chunks * (size_t)(n_cfs + n_expo)));
+    double* d_part = (double*)mcx_scratch(h, 2, sizeof(double) * (size_t)n_chunks * (size_t)(n_cfs + n_expo));
+    if (!d_part) return -100;
     MCX_HIP(h, hipMemsetAsync(d_part, 0, sizeof(double) * (size_t)n_chunks * (size_t)(n_cfs + n_expo), s));
     a.cfs = n_cfs ? d_part : nullptr;
     a.expo = n_expo ? d_part + (size_t)n_chunks * n_cfs : nullptr;
     hipLaunchKernelGGL(k2_eval_book, dim3(grid, n_chunks), dim3(MCX_BLOCK), 0, s, a);
     if (n_cfs) hipLaunchKernelGGL(k2_sum_chunks, dim3((unsigned)((n_cfs + MCX_BLOCK - 1) / MCX_BLOCK)), dim3(MCX_BLOCK), 0, s, a.cfs, n_chunks, n_cfs, d_cfs);
     if (n_expo) hipLaunchKernelGGL(k2_sum_chunks, dim3((unsigned)((n_expo + MCX_BLOCK - 1) / MCX_BLOCK)), dim3(MCX_BLOCK), 0, s, a.expo, n_chunks, n_expo, d_expo);
-    hipError_t e1 = hipGetLastError();
-    hipError_t e2 = hipStreamSynchronize(s);
-    hipFree(d_part);
-    MCX_HIP(h, e1);
-    MCX_HIP(h, e2);
-    return 0;
+    MCX_HIP(h, hipGetLastError());
+    return 0;          // stream-ordered (the chunk images live in a scratch buffer of the handle)
 }
 
 extern "C" int mcx_resolve_atoms(mcx_handle* h, const mcx_book* b, const int32_t* h_atom_ids, int32_t n_ids, const double* d_paths,
@@ -240,15 +236,11 @@ extern "C" int mcx_resolve_atoms(mcx_handle* h, const mcx_book* b, const int32_t
     for (int q = 0; q < n_ids; ++q)
         if (h_atom_ids[q] < 0 || h_atom_ids[q] >= b->n_atoms) MCX_FAIL(h, -2, "mcx_resolve_atoms: atom id out of range");
     hipStream_t s = (hipStream_t)stream;
-    int32_t* d_ids = nullptr;
-    MCX_HIP(h, hipMalloc(&d_ids, sizeof(int32_t) * (size_t)n_ids));
-    MCX_HIP(h, hipMemcpyAsync(d_ids, h_atom_ids, sizeof(int32_t) * (size_t)n_ids, hipMemcpyHostToDevice, s));
-    MCX_HIP(h, hipStreamSynchronize(s));
+    const int32_t* d_ids = (const int32_t*)mcx_stage_small(h, h_atom_ids, sizeof(int32_t) * (size_t)n_ids, s);
+    if (!d_ids) return -100;
     const int gx = (int)((n_paths + MCX_BLOCK - 1) / MCX_BLOCK);
     hipLaunchKernelGGL(k2_resolve, dim3(gx, n_ids), dim3(MCX_BLOCK), 0, s, b->d_atoms, d_ids, n_ids, d_paths, (int64_t)b->n_state,
                        n_paths, ld, d_out, ld_out);
     MCX_HIP(h, hipGetLastError());
-    MCX_HIP(h, hipStreamSynchronize(s));
-    MCX_HIP(h, hipFree(d_ids));
-    return 0;
+    return 0;          // stream-ordered
 }

@@ -470,10 +470,8 @@ extern "C" int mcx_lsm_stats(mcx_handle* h, const mcx_book* b, const int32_t* h_
     if ((size_t)n_ids * grid * 2 * sizeof(double) + (size_t)n_ids * 2 * sizeof(double) > h->ws_bytes || n_ids > 65535 ||
         (size_t)n_ids * 2 * sizeof(double) > h->pinned_bytes)
         MCX_FAIL(h, -2, "mcx_lsm_stats: too many atoms in one call");
-    int32_t* d_ids = nullptr;
-    MCX_HIP(h, hipMalloc(&d_ids, sizeof(int32_t) * (size_t)n_ids));
-    MCX_HIP(h, hipMemcpyAsync(d_ids, h_atom_ids, sizeof(int32_t) * (size_t)n_ids, hipMemcpyHostToDevice, s));
-    MCX_HIP(h, hipStreamSynchronize(s));
+    const int32_t* d_ids = (const int32_t*)mcx_stage_small(h, h_atom_ids, sizeof(int32_t) * (size_t)n_ids, s);
+    if (!d_ids) return -100;
     double* part = h->d_ws;
     double* d_out = h->d_ws + (size_t)n_ids * grid * 2;
     hipLaunchKernelGGL(k3_minmax, dim3(grid, n_ids), dim3(MCX_BLOCK), 0, s, b->d_atoms, d_ids, d_paths, (int64_t)b->n_state, n_paths, ld, part);
@@ -482,7 +480,6 @@ extern "C" int mcx_lsm_stats(mcx_handle* h, const mcx_book* b, const int32_t* h_
     MCX_HIP(h, hipMemcpyAsync(h->h_pinned, d_out, sizeof(double) * 2 * (size_t)n_ids, hipMemcpyDeviceToHost, s));
     MCX_HIP(h, hipStreamSynchronize(s));
     memcpy(h_out, h->h_pinned, sizeof(double) * 2 * (size_t)n_ids);
-    MCX_HIP(h, hipFree(d_ids));
     return 0;
 }
 
@@ -553,9 +550,9 @@ extern "C" int mcx_lsm_run(mcx_handle* h, mcx_book* b, int32_t product, const mc
             if (h_dates[d].coeff_off[w] >= 0 && h_dates[d].coeff_off[w] + (int64_t)S * K > b->n_coeffs)
                 MCX_FAIL(h, -2, "mcx_lsm_run: date %d coefficient offset out of range", d);
     hipStream_t s = (hipStream_t)stream;
-    // workspace of the run: [moments NM | table n_dates*S*K | status n_dates]; freed on every exit path
-    double* d_ws = nullptr;
-    MCX_HIP(h, hipMalloc(&d_ws, sizeof(double) * NM + tab_bytes + st_bytes + 64));
+    // workspace of the run: [moments NM | table n_dates*S*K | status n_dates], a scratch buffer of the handle
+    double* d_ws = (double*)mcx_scratch(h, 1, sizeof(double) * NM + tab_bytes + st_bytes + 64);
+    if (!d_ws) return -100;
     double* d_mom = d_ws;
     double* d_tab = d_ws + NM;
     int32_t* d_st = (int32_t*)(d_tab + (size_t)n_dates * S * K);
@@ -575,7 +572,6 @@ extern "C" int mcx_lsm_run(mcx_handle* h, mcx_book* b, int32_t product, const mc
     if (rc == 0 && (hipMemcpyAsync(h_coeffs, d_tab, tab_bytes, hipMemcpyDeviceToHost, s) != hipSuccess ||
                     hipMemcpyAsync(h_status, d_st, st_bytes, hipMemcpyDeviceToHost, s) != hipSuccess)) { h->err = "mcx_lsm_run: copy failed"; rc = -100; }
     if (hipStreamSynchronize(s) != hipSuccess && rc == 0) { h->err = "mcx_lsm_run: synchronise failed"; rc = -100; }
-    hipFree(d_ws);
     return rc;
 }
 
@@ -608,12 +604,11 @@ extern "C" int mcx_lsm_step_batch(mcx_handle* h, const mcx_book* b, const mcx_ls
     // few paths per product are the norm for big books: one block per 256 paths, capped
     int bpj = mcx_grid_for(n_paths, MCX_BLOCK, 64);
     const int max_jobs = 32768;
-    K3Job* d_jobs = nullptr;
-    double *d_part = nullptr, *d_out = nullptr;
     const int chunk = n_jobs < max_jobs ? n_jobs : max_jobs;
-    MCX_HIP(h, hipMalloc(&d_jobs, sizeof(K3Job) * (size_t)chunk));
-    MCX_HIP(h, hipMalloc(&d_part, sizeof(double) * (size_t)chunk * bpj * NM));
-    MCX_HIP(h, hipMalloc(&d_out, sizeof(double) * (size_t)chunk * NM));
+    K3Job* d_jobs = (K3Job*)mcx_scratch(h, 1, sizeof(K3Job) * (size_t)chunk);
+    double* d_part = (double*)mcx_scratch(h, 2, sizeof(double) * (size_t)chunk * bpj * NM);
+    double* d_out = (double*)mcx_scratch(h, 3, sizeof(double) * (size_t)chunk * NM);
+    if (!d_jobs || !d_part || !d_out) return -100;
     K3Args a;
     memset(&a, 0, sizeof(a));
     a.terms = b->d_terms; a.events = b->d_events; a.atoms = b->d_atoms; a.coeffs = b->d_coeffs; a.paths = d_paths;
@@ -641,7 +636,6 @@ extern "C" int mcx_lsm_step_batch(mcx_handle* h, const mcx_book* b, const mcx_ls
         if (hipMemcpyAsync(h_moments + (size_t)j0 * NM, d_out, sizeof(double) * (size_t)nj * NM, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = -100; break; }
         if (hipStreamSynchronize(s) != hipSuccess) { rc = -100; break; }
     }
-    hipFree(d_jobs); hipFree(d_part); hipFree(d_out);
     if (rc == -1) MCX_FAIL(h, -3, "mcx_lsm_step_batch: unsupported (basis=%d, states=%d)", K, S);
     if (rc != 0) MCX_FAIL(h, -100, "mcx_lsm_step_batch: HIP error: %s", hipGetErrorString(hipGetLastError()));
     return 0;
@@ -655,15 +649,13 @@ extern "C" int mcx_book_set_coeffs_batch(mcx_handle* h, mcx_book* b, const int64
     for (int j = 0; j < n; ++j)
         if (h_offsets[j] < 0 || h_offsets[j] + len > b->n_coeffs) MCX_FAIL(h, -2, "mcx_book_set_coeffs_batch: range %d out of bounds", j);
     hipStream_t s = (hipStream_t)stream;
-    int64_t* d_off = nullptr;
-    double* d_val = nullptr;
-    MCX_HIP(h, hipMalloc(&d_off, sizeof(int64_t) * (size_t)n));
-    MCX_HIP(h, hipMalloc(&d_val, sizeof(double) * (size_t)n * len));
+    int64_t* d_off = (int64_t*)mcx_scratch(h, 1, sizeof(int64_t) * (size_t)n);
+    double* d_val = (double*)mcx_scratch(h, 2, sizeof(double) * (size_t)n * len);
+    if (!d_off || !d_val) return -100;
     MCX_HIP(h, hipMemcpyAsync(d_off, h_offsets, sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, s));
     MCX_HIP(h, hipMemcpyAsync(d_val, h_values, sizeof(double) * (size_t)n * len, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k3_scatter_coeffs, dim3(n), dim3(64), 0, s, d_off, d_val, len, b->d_coeffs);
     MCX_HIP(h, hipGetLastError());
     MCX_HIP(h, hipStreamSynchronize(s));
-    hipFree(d_off); hipFree(d_val);
     return 0;
 }

@@ -121,9 +121,7 @@ extern "C" int mcx_reduce_profiles(mcx_handle* h, const mcx_unsecured_desc* u, c
     double* shifts = h->d_ws + (size_t)gx * R * 2;
     hipLaunchKernelGGL(k4_profiles, dim3(gx, u->n_dates), dim3(MCX_BLOCK), 0, s, du, d_expo_ns, n_paths, ld, part, shifts);
     MCX_HIP(h, hipGetLastError());
-    rc = mcx_finish_acc(h, part, R, gx, (double)n_paths, shifts, h_out, s);
-    hipFree(tmp);
-    return rc;
+    return mcx_finish_acc(h, part, R, gx, (double)n_paths, shifts, h_out, s);
 }
 
 extern "C" int mcx_reduce_cva(mcx_handle* h, const mcx_book* b, const mcx_unsecured_desc* u, const int32_t* h_surv_atoms,
@@ -141,22 +139,23 @@ extern "C" int mcx_reduce_cva(mcx_handle* h, const mcx_book* b, const mcx_unsecu
     DevUnsec du; int32_t* tmp = nullptr;
     int rc = mcx_upload_unsec(h, u, &du, &tmp, s);
     if (rc) return rc;
-    int32_t* d_ids = nullptr;
-    double* d_v = nullptr;
-    MCX_HIP(h, hipMalloc(&d_ids, sizeof(int32_t) * 2 * (size_t)(nd > 0 ? nd : 1)));
-    MCX_HIP(h, hipMalloc(&d_v, sizeof(double) * (size_t)n_paths));
+    for (int m = 0; m < u->n_dates; ++m)          // the rows index the netting set's exposure block of the book
+        if (u->row[m] < 0 || u->row[m] >= b->n_expo_rows || (u->delayed && u->delayed[m] >= b->n_expo_rows))
+            MCX_FAIL(h, -2, "mcx_reduce_cva: exposure row of metric date %d out of range", m);
+    double* d_v = mcx_path_scratch(h, (size_t)n_paths);
+    if (!d_v) return -100;
+    const int32_t* d_ids = nullptr;
     if (nd > 0) {
-        MCX_HIP(h, hipMemcpyAsync(d_ids, h_surv_atoms, sizeof(int32_t) * nd, hipMemcpyHostToDevice, s));
-        MCX_HIP(h, hipMemcpyAsync(d_ids + nd, h_cond_atoms, sizeof(int32_t) * nd, hipMemcpyHostToDevice, s));
-        MCX_HIP(h, hipStreamSynchronize(s));
+        std::vector<int32_t> ids(h_surv_atoms, h_surv_atoms + nd);
+        ids.insert(ids.end(), h_cond_atoms, h_cond_atoms + nd);
+        d_ids = (const int32_t*)mcx_stage_small(h, ids.data(), sizeof(int32_t) * ids.size(), s);
+        if (!d_ids) return -100;
     }
     const int grid = (int)((n_paths + MCX_BLOCK - 1) / MCX_BLOCK);
     hipLaunchKernelGGL(k4_cva_paths, dim3(grid), dim3(MCX_BLOCK), 0, s, du, b->d_atoms, d_ids, d_ids + nd, 1.0 - recovery, d_expo_ns,
                        d_paths, (int64_t)b->n_state, n_paths, ld_expo, ld_paths, d_v);
     MCX_HIP(h, hipGetLastError());
-    rc = reduce_vector_dev(h, d_v, n_paths, h_out, s);
-    hipFree(d_ids); hipFree(d_v); hipFree(tmp);
-    return rc;
+    return reduce_vector_dev(h, d_v, n_paths, h_out, s);
 }
 
 extern "C" int mcx_unsecured(mcx_handle* h, const mcx_unsecured_desc* u, const double* d_expo_ns, int64_t n_paths, int64_t ld,
@@ -172,6 +171,5 @@ extern "C" int mcx_unsecured(mcx_handle* h, const mcx_unsecured_desc* u, const d
     hipLaunchKernelGGL(k4_unsecured, dim3(gx, u->n_dates), dim3(MCX_BLOCK), 0, s, du, d_expo_ns, n_paths, ld, d_out, ld_out);
     MCX_HIP(h, hipGetLastError());
     MCX_HIP(h, hipStreamSynchronize(s));
-    hipFree(tmp);
     return 0;
 }

@@ -700,15 +700,19 @@ extern "C" int mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_boo
         return bytes ? hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
     };
     prog.resize(prog.size() + 4096, 0);       // slack so the fixed-size prefetch of the last chunk stays in bounds
-    MCX_HIP(h, up((void**)&f->d_prog, prog.data(), prog.size()));
-    MCX_HIP(h, up((void**)&f->d_fast, fast.data(), sizeof(FastDate) * fast.size()));
     lterms.resize(lterms.size() + 1);          // never empty
-    MCX_HIP(h, up((void**)&f->d_lterms, lterms.data(), sizeof(LeanTerm) * lterms.size()));
-    MCX_HIP(h, up((void**)&f->d_date_off, date_off.data(), sizeof(int32_t) * date_off.size()));
-    MCX_HIP(h, up((void**)&f->d_date_row, date_row.data(), sizeof(int32_t) * date_row.size()));
     f->partial_bytes = sizeof(double) * 4 * (size_t)n_rec * 2048;
-    MCX_HIP(h, hipMalloc(&f->d_partials, f->partial_bytes));
-    MCX_HIP(h, hipMalloc(&f->d_out, sizeof(mcx_acc) * (size_t)n_rec));
+    hipError_t e = up((void**)&f->d_prog, prog.data(), prog.size());
+    if (e == hipSuccess) e = up((void**)&f->d_fast, fast.data(), sizeof(FastDate) * fast.size());
+    if (e == hipSuccess) e = up((void**)&f->d_lterms, lterms.data(), sizeof(LeanTerm) * lterms.size());
+    if (e == hipSuccess) e = up((void**)&f->d_date_off, date_off.data(), sizeof(int32_t) * date_off.size());
+    if (e == hipSuccess) e = up((void**)&f->d_date_row, date_row.data(), sizeof(int32_t) * date_row.size());
+    if (e == hipSuccess) e = hipMalloc(&f->d_partials, f->partial_bytes);
+    if (e == hipSuccess) e = hipMalloc(&f->d_out, sizeof(mcx_acc) * (size_t)n_rec);
+    if (e != hipSuccess) {                                   // nothing leaks: the partially built object is destroyed
+        mcx_fused_destroy(f);
+        MCX_FAIL(h, -100 - (int)e, "mcx_fused_create: %s", hipGetErrorString(e));
+    }
     *out = f;
     return 0;
 }

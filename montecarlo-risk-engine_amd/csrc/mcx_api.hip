@@ -15,16 +15,16 @@ extern "C" int mcx_create(mcx_handle** out, int device_id)
     h->n_cu = h->prop.multiProcessorCount;
     h->ws_bytes = 8u << 20;
     h->pinned_bytes = 1u << 20;
-    h->d_ws = nullptr;
-    h->h_pinned = nullptr;
+    h->small_bytes = 1u << 20; h->small_cursor = 0;
+    h->d_ws = nullptr; h->h_pinned = nullptr; h->d_small = nullptr; h->h_small = nullptr; h->d_acc = nullptr;
+    for (int q = 0; q < 4; ++q) { h->scratch[q] = nullptr; h->scratch_bytes[q] = 0; }
     h->comm = nullptr; h->comm_ranks = 1; h->comm_rank = 0;
-    if (hipMalloc(&h->d_ws, h->ws_bytes) != hipSuccess) { delete h; return -5; }
-    if (hipHostMalloc(&h->h_pinned, h->pinned_bytes, hipHostMallocDefault) != hipSuccess) { hipFree(h->d_ws); delete h; return -6; }
-    h->small_bytes = 1u << 20; h->small_cursor = 0; h->d_small = nullptr; h->h_small = nullptr;
-    if (hipMalloc((void**)&h->d_small, h->small_bytes) != hipSuccess ||
-        hipHostMalloc((void**)&h->h_small, h->small_bytes, hipHostMallocDefault) != hipSuccess) {
-        hipFree(h->d_small); hipFree(h->d_ws); hipHostFree(h->h_pinned); delete h; return -7;
-    }
+    const bool ok = hipMalloc(&h->d_ws, h->ws_bytes) == hipSuccess
+                 && hipHostMalloc(&h->h_pinned, h->pinned_bytes, hipHostMallocDefault) == hipSuccess
+                 && hipMalloc(&h->d_acc, h->pinned_bytes) == hipSuccess
+                 && hipMalloc((void**)&h->d_small, h->small_bytes) == hipSuccess
+                 && hipHostMalloc((void**)&h->h_small, h->small_bytes, hipHostMallocDefault) == hipSuccess;
+    if (!ok) { mcx_destroy(h); return -5; }
     *out = h;
     return 0;
 }
@@ -37,6 +37,8 @@ extern "C" void mcx_destroy(mcx_handle* h)
     hipHostFree(h->h_pinned);
     hipFree(h->d_small);
     hipHostFree(h->h_small);
+    for (int q = 0; q < 4; ++q) hipFree(h->scratch[q]);
+    hipFree(h->d_acc);
     delete h;
 }
 
@@ -65,22 +67,27 @@ extern "C" int mcx_book_create(mcx_handle* h, const mcx_book_desc* d, mcx_book**
     if (d->n_basis < 1 || d->n_basis > MCX_MAX_BASIS) MCX_FAIL(h, -2, "mcx_book_create: n_basis %d out of range", d->n_basis);
     if (d->n_state < 1 || d->n_state > MCX_MAX_STATE) MCX_FAIL(h, -2, "mcx_book_create: n_state %d out of range", d->n_state);
     // validate every index the kernels will dereference (a wild index on the GPU can take the whole node down)
+    if (d->n_dates < 1) MCX_FAIL(h, -2, "mcx_book_create: n_dates %d out of range", d->n_dates);
     for (int i = 0; i < d->n_atoms; ++i)
-        if (d->atoms[i].col >= d->n_state || d->atoms[i].t_idx < 0) MCX_FAIL(h, -3, "mcx_book_create: atom %d out of range", i);
+        if (d->atoms[i].col >= d->n_state || d->atoms[i].t_idx < 0 || d->atoms[i].t_idx >= d->n_dates)
+            MCX_FAIL(h, -3, "mcx_book_create: atom %d out of range", i);
     for (int i = 0; i < d->n_terms; ++i)
         if (d->terms[i].atom < 0 || d->terms[i].atom >= d->n_atoms || d->terms[i].den >= d->n_atoms)
             MCX_FAIL(h, -3, "mcx_book_create: term %d references a bad atom", i);
     for (int i = 0; i < d->n_events; ++i) {
         const mcx_event& e = d->events[i];
         if (e.kind < MCX_EV_CASHFLOW || e.kind > MCX_EV_EXPO_BS) MCX_FAIL(h, -3, "mcx_book_create: event %d has a bad kind", i);
+        if (e.t_idx < 0 || e.t_idx >= d->n_dates) MCX_FAIL(h, -3, "mcx_book_create: event %d date out of range", i);
         if (e.num_atom < 0 || e.num_atom >= d->n_atoms || e.x_atom >= d->n_atoms) MCX_FAIL(h, -3, "mcx_book_create: event %d atoms", i);
         if (e.term_begin < 0 || e.term_end < e.term_begin || e.term_end > d->n_terms) MCX_FAIL(h, -3, "mcx_book_create: event %d terms", i);
-        if (e.coeff_off >= 0 && e.coeff_off + MCX_MAX_STATES * d->n_basis > d->n_coeffs + MCX_MAX_STATES * d->n_basis)
-            MCX_FAIL(h, -3, "mcx_book_create: event %d coefficient offset", i);
+        if (e.coeff_off >= d->n_coeffs) MCX_FAIL(h, -3, "mcx_book_create: event %d coefficient offset", i);   // (block extent: per product below)
         if ((e.kind == MCX_EV_EXERCISE && e.coeff_off >= 0 && e.x_atom < 0) || (e.kind >= MCX_EV_EXPO_POLY && e.x_atom < 0))
             MCX_FAIL(h, -3, "mcx_book_create: event %d needs an explanatory atom", i);
         if (e.kind == MCX_EV_OPTION && e.aux[0] == 5.0 && (e.coeff_off < 0 || e.coeff_off + 2 > d->n_coeffs))
             MCX_FAIL(h, -3, "mcx_book_create: bridge barrier event %d needs two parameters at coeff_off", i);
+        if (e.kind == MCX_EV_OPTION && e.aux[0] == 5.0 && d->coeffs &&
+            !(d->coeffs[e.coeff_off + 1] >= 0.0 && d->coeffs[e.coeff_off + 1] < (double)d->n_products))
+            MCX_FAIL(h, -3, "mcx_book_create: bridge barrier event %d: draw id outside [0, n_products)", i);
         if (e.kind == MCX_EV_OPTION && (e.aux[0] == 4.0 || e.aux[0] == 5.0) && (e.x_atom < 0 || ((int)e.aux[3] & 7) < 1 || ((int)e.aux[3] & 7) > 4 || ((int)e.aux[3] >> 3) > 4))
             MCX_FAIL(h, -3, "mcx_book_create: barrier event %d needs the maturity spot in x_atom and barrier types in 1..4", i);
         if (e.kind == MCX_EV_OPTION && e.aux[0] == 3.0 && !(e.aux[2] > 0.0)) MCX_FAIL(h, -3, "mcx_book_create: binary event %d needs eps > 0", i);
@@ -168,21 +175,21 @@ extern "C" int mcx_book_create(mcx_handle* h, const mcx_book_desc* d, mcx_book**
     b->d_atoms = nullptr; b->d_terms = nullptr; b->d_events = nullptr; b->d_products = nullptr; b->d_coeffs = nullptr;
     b->d_bridge = nullptr; b->d_bridge_inject = nullptr;
     b->ex_mode = 0; b->d_ex_bits = nullptr; b->ex_ld = 0;
-    MCX_HIP(h, hipMalloc(&b->d_atoms, sizeof(DevAtom) * atoms.size()));
-    MCX_HIP(h, hipMalloc(&b->d_terms, sizeof(DevTerm) * terms.size()));
-    MCX_HIP(h, hipMalloc(&b->d_events, sizeof(DevEvent) * events.size()));
-    MCX_HIP(h, hipMalloc(&b->d_products, sizeof(DevProduct) * (b->h_products.size() ? b->h_products.size() : 1)));
-    MCX_HIP(h, hipMalloc(&b->d_coeffs, sizeof(double) * (size_t)(d->n_coeffs > 0 ? d->n_coeffs : 1)));
-    MCX_HIP(h, hipMalloc(&b->d_bridge, sizeof(DevBridge)));
-    MCX_HIP(h, hipMemset(b->d_bridge, 0, sizeof(DevBridge)));
-    MCX_HIP(h, hipMalloc(&b->d_bridge_inject, sizeof(double*) * (size_t)(d->n_products > 0 ? d->n_products : 1)));
-    MCX_HIP(h, hipMemcpy(b->d_atoms, atoms.data(), sizeof(DevAtom) * atoms.size(), hipMemcpyHostToDevice));
-    MCX_HIP(h, hipMemcpy(b->d_terms, terms.data(), sizeof(DevTerm) * terms.size(), hipMemcpyHostToDevice));
-    MCX_HIP(h, hipMemcpy(b->d_events, events.data(), sizeof(DevEvent) * events.size(), hipMemcpyHostToDevice));
-    if (!b->h_products.empty())
-        MCX_HIP(h, hipMemcpy(b->d_products, b->h_products.data(), sizeof(DevProduct) * b->h_products.size(), hipMemcpyHostToDevice));
-    if (d->n_coeffs > 0)
-        MCX_HIP(h, hipMemcpy(b->d_coeffs, d->coeffs, sizeof(double) * (size_t)d->n_coeffs, hipMemcpyHostToDevice));
+    auto upload = [&](void** dst, const void* src, size_t bytes) -> bool {        // false: the error is in h->err; the caller frees
+        hipError_t e = hipMalloc(dst, bytes ? bytes : 8);
+        if (e == hipSuccess && src && bytes) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { h->err = std::string("mcx_book_create: ") + hipGetErrorString(e); return false; }
+        return true;
+    };
+    bool ok = upload((void**)&b->d_atoms, atoms.data(), sizeof(DevAtom) * atoms.size())
+           && upload((void**)&b->d_terms, terms.data(), sizeof(DevTerm) * terms.size())
+           && upload((void**)&b->d_events, events.data(), sizeof(DevEvent) * events.size())
+           && upload((void**)&b->d_products, b->h_products.data(), sizeof(DevProduct) * b->h_products.size())
+           && upload((void**)&b->d_coeffs, d->n_coeffs > 0 ? d->coeffs : nullptr, sizeof(double) * (size_t)(d->n_coeffs > 0 ? d->n_coeffs : 1))
+           && upload((void**)&b->d_bridge, nullptr, sizeof(DevBridge))
+           && upload((void**)&b->d_bridge_inject, nullptr, sizeof(double*) * (size_t)(d->n_products > 0 ? d->n_products : 1));
+    if (ok && hipMemset(b->d_bridge, 0, sizeof(DevBridge)) != hipSuccess) { h->err = "mcx_book_create: hipMemset failed"; ok = false; }
+    if (!ok) { mcx_book_destroy(b); return -100; }
     *out = b;
     return 0;
 }
@@ -239,6 +246,17 @@ extern "C" int mcx_book_set_exercise_replay(mcx_handle* h, mcx_book* b, int32_t 
 }
 
 // ---- shared helpers ---------------------------------------------------------------------------------------------------
+void* mcx_scratch(mcx_handle* h, int slot, size_t bytes)
+{
+    if (bytes <= h->scratch_bytes[slot] && h->scratch[slot]) return h->scratch[slot];
+    hipFree(h->scratch[slot]);               // (synchronises: only when a call needs more than any call before it)
+    h->scratch[slot] = nullptr; h->scratch_bytes[slot] = 0;
+    const size_t want = bytes < 4096 ? 4096 : bytes;
+    if (hipMalloc(&h->scratch[slot], want) != hipSuccess) { h->err = "hipMalloc of a scratch buffer failed"; return nullptr; }
+    h->scratch_bytes[slot] = want;
+    return h->scratch[slot];
+}
+
 void* mcx_stage_small(mcx_handle* h, const void* src, size_t bytes, hipStream_t s)
 {
     const size_t need = (bytes + 255) & ~(size_t)255;
@@ -295,13 +313,11 @@ int mcx_finish_acc(mcx_handle* h, const double* d_partials, int n_records, int n
                    const double* d_shifts, mcx_acc* h_out, hipStream_t s)
 {
     if ((size_t)n_records * sizeof(mcx_acc) > h->pinned_bytes) MCX_FAIL(h, -2, "too many accumulator records");
-    mcx_acc* d_out = nullptr;
-    MCX_HIP(h, hipMalloc(&d_out, sizeof(mcx_acc) * (size_t)n_records));
+    mcx_acc* d_out = (mcx_acc*)h->d_acc;
     hipLaunchKernelGGL(k_finish_acc, dim3(n_records), dim3(MCX_BLOCK), 0, s, d_partials, n_records, n_blocks, n_paths, d_shifts, d_out);
     MCX_HIP(h, hipGetLastError());
     MCX_HIP(h, hipMemcpyAsync(h->h_pinned, d_out, sizeof(mcx_acc) * (size_t)n_records, hipMemcpyDeviceToHost, s));
     MCX_HIP(h, hipStreamSynchronize(s));
     memcpy(h_out, h->h_pinned, sizeof(mcx_acc) * (size_t)n_records);
-    MCX_HIP(h, hipFree(d_out));
     return 0;
 }

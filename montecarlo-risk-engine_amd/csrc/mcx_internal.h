@@ -30,6 +30,9 @@ struct mcx_handle {
     unsigned char* d_small;
     unsigned char* h_small;
     size_t small_bytes, small_cursor;
+    void* d_acc;           // device image of the accumulator records of a reduction call (pinned_bytes large)
+    void* scratch[4];      // device scratch buffers of the entry points, grown on demand and freed with the handle
+    size_t scratch_bytes[4];
     void* comm;            // ncclComm_t of mcx_comm_init (mcx_comm.hip) or nullptr
     int comm_ranks, comm_rank;
 };
@@ -251,6 +254,10 @@ __device__ __forceinline__ double dev_barrier_ind(int type, double b, double mx,
 }
 
 // host-side helpers implemented in mcx_api.hip
+// device scratch buffer `slot` (0..3) of at least `bytes` bytes, owned by the handle: no hipMalloc / hipFree per call (a buffer
+// is re-allocated only when a call needs more than any call before it); nullptr + handle error on failure
+void* mcx_scratch(mcx_handle* h, int slot, size_t bytes);
+static inline double* mcx_path_scratch(mcx_handle* h, size_t n) { return (double*)mcx_scratch(h, 0, sizeof(double) * n); }
 // copy `bytes` of host data to device memory that stays valid for the kernels enqueued on `s` by the current API call (a ring:
 // wrapping synchronises the stream first); returns nullptr and sets the handle's error on failure
 void* mcx_stage_small(mcx_handle* h, const void* src, size_t bytes, hipStream_t s);

@@ -51,7 +51,7 @@ class SimDesc(C.Structure):
 class BookDesc(C.Structure):
     _fields_ = [("n_atoms", C.c_int32), ("n_terms", C.c_int32), ("n_events", C.c_int32), ("n_products", C.c_int32),
                 ("n_netting_sets", C.c_int32), ("n_expo_rows", C.c_int32), ("n_basis", C.c_int32), ("n_coeffs", C.c_int32),
-                ("want_cfs", C.c_int32), ("want_expo", C.c_int32), ("n_state", C.c_int32), ("reserved", C.c_int32),
+                ("want_cfs", C.c_int32), ("want_expo", C.c_int32), ("n_state", C.c_int32), ("n_dates", C.c_int32),
                 ("atoms", C.c_void_p), ("terms", C.c_void_p), ("events", C.c_void_p), ("products", C.c_void_p),
                 ("coeffs", C.c_void_p)]
 

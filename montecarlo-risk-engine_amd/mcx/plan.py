@@ -207,6 +207,7 @@ class BookPlan:
         d.n_netting_sets, d.n_expo_rows, d.n_basis, d.n_coeffs = n_netting_sets, n_expo_rows, comp.n_basis, len(self.coeffs)
         d.want_cfs, d.want_expo = int(want_cfs), int(want_expo)
         d.n_state = n_state
+        d.n_dates = len(comp.time_to_index)
         d.atoms, d.terms, d.events, d.products = (_abi.ptr(self.atoms), _abi.ptr(self.terms), _abi.ptr(self.events),
                                                   _abi.ptr(self.products))
         d.coeffs = _abi.ptr(self.coeffs)
