@@ -61,3 +61,14 @@ def test_hull_white_gpu_vs_oracle(hip, oracle):
         g = MonteCarloEngine(tl, scheme, hw, 8192, 5, backend=hip).generate_paths_native().cpu().numpy()
         c = MonteCarloEngine(tl, scheme, hw, 8192, 5, backend=oracle).generate_paths_native().numpy()
         assert np.allclose(g, c, rtol=1e-10, atol=1e-13)
+
+
+@pytest.mark.gpu
+def test_hull_white_reprices_input_curve_on_the_gpu(hip):
+    """parity of the Hull-White slot is UNPINNED (the reference's models/hull_white.py is an unimportable draft); its anchor
+    on the GPU is the property the fitted theta(t) exists for: E[exp(-int_0^T r)] = P(0, T) of the input curve, 1 M paths"""
+    hw = _hw()
+    p = MonteCarloEngine(np.array([0.0, 2.0]), SimulationScheme.ANALYTICAL, hw, 1 << 20, 200, backend=hip).generate_paths_native().cpu().numpy()
+    df = np.exp(-p[1, 1])
+    se = df.std(ddof=1) / math.sqrt(df.size)
+    assert abs(df.mean() - hw.discount_curve(2.0)) < 4 * se + 2e-5, (df.mean(), hw.discount_curve(2.0), se)
