@@ -87,7 +87,7 @@ __device__ __forceinline__ void lean_record(const double (&v)[PPL], const bool (
 template <int NSLOT, int SIG, int PPL, bool STORE>
 __device__ __forceinline__ void lean_date(int t, const int64_t (&i)[PPL], const bool (&live)[PPL], bool first_tile,
                                           double* __restrict__ lds, const double (&reg)[PPL][2 * NSLOT], double (&cfs)[PPL], double (&cva)[PPL],
-                                          int (&est)[PPL])
+                                          int (&est)[PPL], const double* __restrict__ etab)
 {
     // (state registers are indexed by wave-uniform record fields: M0-relative VGPR reads; mcx_fused_create binds an absent
     // reference to register 0 with a zero coefficient, so no range test is needed)
@@ -95,7 +95,7 @@ __device__ __forceinline__ void lean_date(int t, const int64_t (&i)[PPL], const 
     KArgs& a = kargs_region(zd);
     const FastDate* __restrict__ fp = a.fast + t;
     const auto& k = a.k1;
-    const mcx_exp_coef ec = mcx_exp_load(zd);
+    const mcx_expq_coef ec = mcx_expq_load(zd);       // exponentials: table of 2^(j/128) in LDS + degree-5 remainder
     if (STORE && k.paths) {
 #pragma unroll
         for (int q = 0; q < PPL; ++q) if (live[q]) sim_store_state<NSLOT, SIG>(k, t, i[q], reg[q]);
@@ -115,7 +115,7 @@ __device__ __forceinline__ void lean_date(int t, const int64_t (&i)[PPL], const 
             const double c0 = FD(ni_c0), c1 = FD(ni_c1);
             const int r = FD(ni_reg);
 #pragma unroll
-            for (int q = 0; q < PPL; ++q) inv[q] = mcx_exp(fma(c1, reg[q][r], c0), ec);
+            for (int q = 0; q < PPL; ++q) inv[q] = mcx_exp_tab(fma(c1, reg[q][r], c0), etab, ec);
         }
     }
     if (want_cash) {
@@ -129,7 +129,7 @@ __device__ __forceinline__ void lean_date(int t, const int64_t (&i)[PPL], const 
             const double w = FD(t_w[j]), c0 = FD(t_c0[j]), c1 = FD(t_c1[j]);
             const int r = FD(t_reg[j]);
 #pragma unroll
-            for (int q = 0; q < PPL; ++q) val[q] = fma(w, mcx_exp(fma(c1, reg[q][r], c0), ec), val[q]);
+            for (int q = 0; q < PPL; ++q) val[q] = fma(w, mcx_exp_tab(fma(c1, reg[q][r], c0), etab, ec), val[q]);
         }
 #pragma unroll
         for (int q = 0; q < PPL; ++q) cfs[q] = fma(val[q], inv[q], cfs[q]);
@@ -144,11 +144,14 @@ __device__ __forceinline__ void lean_date(int t, const int64_t (&i)[PPL], const 
         double val[PPL];
 #pragma unroll
         for (int q = 0; q < PPL; ++q) val[q] = fma(k1, reg[q][lr], k0);
+        // the next term's record is in flight while this term's two exponentials run (the table has one spare entry at its end)
+        LeanTerm tm = ldk_struct(lt);
 #pragma unroll 1
         for (int j = 0; j < n_t; ++j) {
-            const LeanTerm tm = ldk_struct(lt + j);
+            const LeanTerm nx = ldk_struct(lt + j + 1);
 #pragma unroll
-            for (int q = 0; q < PPL; ++q) val[q] = fma(tm.w, mcx_exp(fma(tm.c1, reg[q][tm.reg], tm.c0), ec), val[q]);
+            for (int q = 0; q < PPL; ++q) val[q] = fma(tm.w, mcx_exp_tab(fma(tm.c1, reg[q][tm.reg], tm.c0), etab, ec), val[q]);
+            tm = nx;
         }
         const double xa = FD(ex_x_a), xd = FD(ex_x_d);
         const int xr = FD(ex_x_reg), co = FD(ex_coeff_off);
@@ -197,7 +200,7 @@ __device__ __forceinline__ void lean_date(int t, const int64_t (&i)[PPL], const 
             const double cc0 = FD(c_c0), cc1 = FD(c_c1);
             const int cr = FD(c_reg);
 #pragma unroll
-            for (int q = 0; q < PPL; ++q) cs[q] = fma(cb, mcx_exp(fma(cc1, reg[q][cr], cc0), ec), ca);
+            for (int q = 0; q < PPL; ++q) cs[q] = fma(cb, mcx_exp_tab(fma(cc1, reg[q][cr], cc0), etab, ec), ca);
         }
     };
     if (merged) {
@@ -205,7 +208,7 @@ __device__ __forceinline__ void lean_date(int t, const int64_t (&i)[PPL], const 
         const int nr = FD(ni_reg), sr = FD(s_reg);
         double w[PPL], cs[PPL];
 #pragma unroll
-        for (int q = 0; q < PPL; ++q) w[q] = mb * mcx_exp(fma(ms1, reg[q][sr], fma(mn1, reg[q][nr], mc0)), ec);
+        for (int q = 0; q < PPL; ++q) w[q] = mb * mcx_exp_tab(fma(ms1, reg[q][sr], fma(mn1, reg[q][nr], mc0)), etab, ec);
         cond_surv(cs);
 #pragma unroll
         for (int q = 0; q < PPL; ++q) cva[q] = fma(fmax(p[q], 0.0), w[q] * (1.0 - cs[q]), cva[q]);
@@ -239,7 +242,7 @@ __device__ __forceinline__ void lean_date(int t, const int64_t (&i)[PPL], const 
             const int sr = FD(s_reg);
             double sp[PPL], cs[PPL];
 #pragma unroll
-            for (int q = 0; q < PPL; ++q) sp[q] = sb * mcx_exp(fma(sc1, reg[q][sr], sc0), ec);
+            for (int q = 0; q < PPL; ++q) sp[q] = sb * mcx_exp_tab(fma(sc1, reg[q][sr], sc0), etab, ec);
             cond_surv(cs);
 #pragma unroll
             for (int q = 0; q < PPL; ++q) cva[q] = fma(fmax(u[q], 0.0), sp[q] * (1.0 - cs[q]), cva[q]);
@@ -263,9 +266,12 @@ __global__ __launch_bounds__(MCX_BLOCK, MCX_LEAN_WAVES) void kf_lean(const Fused
     const int n_rec = a0.n_rec;
     const int64_t n = a0.k1.n;
     for (int q = threadIdx.x; q < 9 * n_rec; q += MCX_BLOCK) lds[q] = 0.0;
-    __shared__ double bm_lds[(INJECT || !SIMULATE) ? 2 : MCX_BM_LDS_DOUBLES];      // Box-Muller lookup tables
+    constexpr int BM = (INJECT || !SIMULATE) ? 0 : MCX_BM_LDS_DOUBLES;
+    __shared__ double tab_lds[BM + MCX_EXP_LDS_DOUBLES];            // Box-Muller lookup tables | exp table
     const double* tab = nullptr;
-    if (!INJECT && SIMULATE) { mcx_bm_load(bm_lds); tab = bm_lds; }
+    const double* etab = tab_lds + BM;
+    mcx_exp_tab_load(tab_lds + BM);
+    if (BM) { mcx_bm_load(tab_lds); tab = tab_lds; }
     __syncthreads();
     const int64_t tiles = (n + TILE - 1) / TILE;
     double n_block = 0.0;
@@ -319,7 +325,7 @@ __global__ __launch_bounds__(MCX_BLOCK, MCX_LEAN_WAVES) void kf_lean(const Fused
                     ++step;
                 }
             }
-            if (st >= 0) lean_date<NSLOT, SIG, PPL, true>(st, i, live, first_tile, lds, reg, cfs, cva, est);
+            if (st >= 0) lean_date<NSLOT, SIG, PPL, true>(st, i, live, first_tile, lds, reg, cfs, cva, est, etab);
         }
         } else {
             double nxt[PPL][NREG];
@@ -345,7 +351,7 @@ __global__ __launch_bounds__(MCX_BLOCK, MCX_LEAN_WAVES) void kf_lean(const Fused
 #pragma unroll
                     for (int r = 0; r < NREG; ++r) reg[q][r] = nxt[q][r];
                 if (t + 1 < n_dates) load_row(t + 1, nxt);            // next date's state streams in while this date's program runs
-                lean_date<NSLOT, SIG, PPL, false>(t, i, live, first_tile, lds, reg, cfs, cva, est);
+                lean_date<NSLOT, SIG, PPL, false>(t, i, live, first_tile, lds, reg, cfs, cva, est, etab);
             }
         }
         {

@@ -180,3 +180,34 @@ __device__ __forceinline__ void mcx_sincos2pi_tab(double u, const double* __rest
     s = fma(sc.x, pc, sc.y * ps);
     c = fma(-sc.x, ps, sc.y * pc);
 }
+
+// ---- table-driven exp for the date programs of kf_lean.hip -----------------------------------------------------------------
+// A Bermudan swaption's exercise value is ~35 zero-bond prices per path and date, each one exponential: with the degree-13
+// polynomial above that is 19 f64 VALU per exponential.  A 128-entry table of 2^(j/128) (1 KiB in LDS, one ds_read_b64 per lane
+// on the otherwise idle LDS pipe) shrinks the reduced argument to |r| <= ln2/256, where a degree-5 polynomial is exact to 5e-19:
+// 12 f64 + 3 integer VALU.  exp(x) = 2^e T[j] (1 + q(r)), x = (128 e + j) ln2/128 + r.  <= ~2 ulp.
+#define MCX_EXP_LDS_DOUBLES 128
+__device__ const double MCX_EXPQ_C[4] __attribute__((aligned(32))) = {0.5, 1.0 / 6.0, 1.0 / 24.0, 1.0 / 120.0};
+struct mcx_expq_coef { double c[4]; };
+__device__ __forceinline__ mcx_expq_coef mcx_expq_load(int z = 0) { return ldk_struct((const mcx_expq_coef*)(MCX_EXPQ_C + z)); }
+
+// cooperative copy of the table into the block's LDS area (MCX_EXP_LDS_DOUBLES doubles); the caller synchronises
+__device__ __forceinline__ void mcx_exp_tab_load(double* __restrict__ tab)
+{
+    for (int q = threadIdx.x; q < MCX_EXP_LDS_DOUBLES; q += blockDim.x) tab[q] = MCX_EXP2_TAB[q];
+}
+
+__device__ __forceinline__ double mcx_exp_tab(double x, const double* __restrict__ tab, const mcx_expq_coef& C)
+{
+    const double k = rint(x * MCX_128_LN2);
+    double r = fma(k, -MCX_LN2_128_HI, x);
+    r = fma(k, -MCX_LN2_128_LO, r);
+    const int ki = (int)k;
+    const double T = tab[ki & 127];
+    double q = fma(C.c[3], r, C.c[2]);
+    q = fma(q, r, C.c[1]);
+    q = fma(q, r, C.c[0]);
+    q = fma(q, r, 1.0);
+    q *= r;                                                  // q = e^r - 1
+    return ldexp(fma(T, q, T), ki >> 7);
+}
