@@ -134,7 +134,7 @@ __device__ __forceinline__ void draw_pair(uint64_t seed, uint64_t path, uint32_t
     const double ub = u53(w2, w3);
     double s, c, r;
     if (TAB) {
-        r = mcx_sqrt(-2.0 * mcx_log_tab(ua, tab, bc));
+        r = mcx_sqrt_g(mcx_m2log_tab(ua, tab, bc));
         mcx_sincos2pi_tab(ub, tab, s, c, bc);
     } else {
         r = mcx_sqrt(-2.0 * mcx_log(ua));
@@ -194,7 +194,7 @@ __device__ __forceinline__ void step_slot(const SL& sl, int scheme_rt, int flags
     }
     case MCX_MODEL_CIRPP: {                                               // cirpp.py:188-198
         const double y = s0;
-        const double sy = mcx_sqrt(y);                    // = sqrt(clamp(y, 0)) of cirpp.py:194: mcx_sqrt returns 0 for y <= 0
+        const double sy = mcx_sqrt_g(y);                  // = sqrt(clamp(y, 0)) of cirpp.py:194: mcx_sqrt_g returns 0 for y <= 0
         const double yn = y + p[0] * (p[1] - y) * dt + p[2] * sy * sq * zc0;
         s1 = s1 + (y + ldk(aux + 0)) * dt;
         s0 = fmax(yn, 1e-12);
@@ -332,11 +332,13 @@ __device__ __forceinline__ void sim_substep(const KA& k, int step, uint64_t path
         }
     }
     const double* __restrict__ L = k.chol + (int64_t)sp.chol_idx * NZ * NZ;     // model.py:48  z @ chol.T
+    // EULER / QE correlate with the factor of a CORRELATION matrix (model.py:66-73): its first entry is sqrt(1) = 1 exactly
+    constexpr bool UNIT_L00 = sig_scheme(SIG) == MCX_SCHEME_EULER || sig_scheme(SIG) == MCX_SCHEME_QE;
 #pragma unroll
     for (int r = 0; r < NZ; ++r) {
         double acc = 0.0;
 #pragma unroll
-        for (int c = 0; c <= r; ++c) acc += ldk(L + r * NZ + c) * z[c];
+        for (int c = 0; c <= r; ++c) acc += (UNIT_L00 && r == 0) ? z[c] : ldk(L + r * NZ + c) * z[c];
         zc[r] = acc;
     }
     const double* __restrict__ ax = k.aux + (int64_t)step * NSLOT * MCX_AUX;

@@ -119,6 +119,19 @@ __device__ __forceinline__ double mcx_sqrt(double a)
     return a > 0.0 ? g : 0.0;
 }
 
+// the same without the residual correction: v_rsq_f64 seed + one coupled Goldschmidt step, error ~1.5 eps_seed^2 (1-2 ulp).  Used
+// where the result feeds a Monte-Carlo increment (Box-Muller radius, CIR diffusion): 3 VALU fewer per root on a kernel that is
+// bound by VALU issue
+__device__ __forceinline__ double mcx_sqrt_g(double a)
+{
+    const double y = __builtin_amdgcn_rsq(a);
+    double g = a * y;
+    const double h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    return a > 0.0 ? g : 0.0;
+}
+
 // ---- table-driven log / sincos for the Box-Muller transform ----------------------------------------------------------
 // The path kernel is bound by f64 VALU issue (4 clk per wave64 instruction), and ~half of a sub-step was the polynomial
 // log + sincos above (35 + 35 instructions).  A 128-entry table per function (2 x 2 KiB in LDS, one ds_read_b128 per lane —
@@ -128,8 +141,10 @@ __device__ __forceinline__ double mcx_sqrt(double a)
 #include "mcx_tables.h"
 #define MCX_BM_LDS_DOUBLES 512
 
-// [0..5] log1p(t) = t + t^2 (c0 + c1 t + ...);  [6..8] sin d = d + d^3 (...);  [9..11] cos d = 1 + d^2 (...)
-__device__ const double MCX_BM_C[12] __attribute__((aligned(64))) = {-0.5, 1.0 / 3.0, -0.25, 0.2, -1.0 / 6.0, 1.0 / 7.0,
+// [0..5] -2 log1p(t) = s + s^2 (c0 + c1 s + ...), s = -2 t: the coefficients of log1p scaled by exact powers of two
+// (c_k' = -c_k (-1/2)^k / 2), so the result is bit for bit -2 x (t + t^2 (-1/2 + t/3 - ...));
+// [6..8] sin d = d + d^3 (...);  [9..11] cos d = 1 + d^2 (...)
+__device__ const double MCX_BM_C[12] __attribute__((aligned(64))) = {0.25, (1.0 / 3.0) * 0.25, 0.03125, 0.2 * 0.0625, (1.0 / 6.0) * 0.03125, (1.0 / 7.0) * 0.015625,
                                                                      -1.0 / 6.0, 1.0 / 120.0, -1.0 / 5040.0, -0.5, 1.0 / 24.0, -1.0 / 720.0};
 struct mcx_bm_coef { double c[12]; };
 __device__ __forceinline__ mcx_bm_coef mcx_bm_coef_load(int z = 0)      // 24 SGPRs; z: region zero (or literal 0)
@@ -141,7 +156,7 @@ __device__ __forceinline__ mcx_bm_coef mcx_bm_coef_load(int z = 0)      // 24 SG
 __device__ __forceinline__ void mcx_bm_load(double* __restrict__ tab)
 {
     for (int q = threadIdx.x; q < 256; q += blockDim.x) {
-        tab[q] = MCX_LOG_TAB[q];
+        tab[q] = -2.0 * MCX_LOG_TAB[q];            // (-2 / c, -2 log c): the radius needs -2 log u (exact scaling)
         tab[256 + q] = MCX_TRIG_TAB[q];
     }
     __syncthreads();
@@ -149,20 +164,21 @@ __device__ __forceinline__ void mcx_bm_load(double* __restrict__ tab)
 
 typedef double mcx_d2 __attribute__((ext_vector_type(2)));
 
-// log(x), x a normal double in (0, 1]
-__device__ __forceinline__ double mcx_log_tab(double x, const double* __restrict__ tab, const mcx_bm_coef& C)
+// -2 log(x), x a normal double in (0, 1]: the squared Box-Muller radius.  Every constant of log(x) = k ln2 + log c + log1p(m/c - 1)
+// carries the factor -2 (table, ln2 split, polynomial: all exact power-of-two scalings), so the product -2 * log costs nothing
+__device__ __forceinline__ double mcx_m2log_tab(double x, const double* __restrict__ tab, const mcx_bm_coef& C)
 {
     const double m = __builtin_amdgcn_frexp_mant(x);                  // [0.5, 1)
     const int e = __builtin_amdgcn_frexp_exp(x);
     const int j = (__double2hiint(m) >> 13) & 127;                     // top 7 mantissa bits
-    const mcx_d2 tc = ((const mcx_d2*)tab)[j];                        // (1/c, log c)
-    const double t = fma(m, tc.x, -1.0);                               // |t| <= 2^-8
+    const mcx_d2 tc = ((const mcx_d2*)tab)[j];                        // (-2/c, -2 log c)
+    const double s = fma(m, tc.x, 2.0);                                // -2 t, |t| <= 2^-8
     double q = C.c[5];
 #pragma unroll
-    for (int k = 4; k >= 0; --k) q = fma(q, t, C.c[k]);
-    const double p = fma(t * t, q, t);                                 // log1p(t)
+    for (int k = 4; k >= 0; --k) q = fma(q, s, C.c[k]);
+    const double p = fma(s * s, q, s);                                 // -2 log1p(t)
     const double dk = (double)e;
-    return fma(dk, 6.93147180369123816490e-01, tc.y) + fma(dk, 1.90821492927058770002e-10, p);
+    return fma(dk, -2.0 * 6.93147180369123816490e-01, tc.y) + fma(dk, -2.0 * 1.90821492927058770002e-10, p);
 }
 
 // (sin, cos)(2 pi u), u in [0, 1]
