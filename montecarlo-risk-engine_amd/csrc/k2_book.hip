@@ -153,6 +153,192 @@ __global__ __launch_bounds__(MCX_BLOCK) void k2_eval_book(const K2Args a)
     if (cur_ns >= 0 && a.want_cfs) cfs_out[(int64_t)cur_ns * a.ld_out + i] = acc_ns;
 }
 
+// ---- PPL paths per lane ---------------------------------------------------------------------------------------------------
+// The one-path-per-lane kernel above is latency-bound at large path counts: a lane walks the event program through a chain of
+// scalar record loads and dependent 8-byte global loads with 4 resident waves per SIMD.  Here a lane carries PPL paths through
+// the same (wave-uniform) program: PPL independent loads in flight per event, every record load and branch paid once per
+// PPL x 64 paths.  Books with barrier events (per-path bridge RNG) and the product-chunked mode stay on the kernel above.
+template <int PPL>
+__device__ __forceinline__ void dev_atoms(const DevAtom& a, const double* __restrict__ paths, int64_t D, int64_t ld, const int64_t (&i)[PPL],
+                                          double (&v)[PPL])
+{
+    double x[PPL];
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) x[q] = a.col >= 0 ? paths[((int64_t)a.t_idx * D + a.col) * ld + i[q]] : 0.0;
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) {
+        v[q] = fma(a.d, x[q], a.a);
+        if (a.b != 0.0) v[q] = fma(a.b, mcx_exp(fma(a.c1, x[q], a.c0)), v[q]);
+    }
+}
+
+template <int PPL>
+__global__ __launch_bounds__(MCX_BLOCK) void k2_eval_book_v(const K2Args a)
+{
+    int64_t i[PPL];
+    bool live[PPL];
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) {
+        const int64_t i_raw = ((int64_t)blockIdx.x * PPL + q) * MCX_BLOCK + threadIdx.x;
+        live[q] = i_raw < a.n;
+        i[q] = live[q] ? i_raw : a.n - 1;
+    }
+    if (!live[0]) return;
+    const int64_t D = a.n_state, ld = a.ld;
+    const int K = a.n_basis;
+    int cur_ns = -1;
+    double acc_ns[PPL];
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) acc_ns[q] = 0.0;
+    for (int p = 0; p < a.n_products; ++p) {
+        const DevProduct pr = ldk_struct(&a.products[p]);
+        if (pr.ev_end == pr.ev_begin) continue;
+        if (pr.netting_set != cur_ns) {
+            if (cur_ns >= 0 && a.want_cfs) {
+#pragma unroll
+                for (int q = 0; q < PPL; ++q) if (live[q]) a.cfs[(int64_t)cur_ns * a.ld_out + i[q]] = acc_ns[q];
+            }
+            cur_ns = pr.netting_set;
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) acc_ns[q] = 0.0;
+        }
+        int s[PPL];
+        double acc[PPL];
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) { s[q] = pr.init_state; acc[q] = 0.0; }
+        for (int e_i = pr.ev_begin; e_i < pr.ev_end; ++e_i) {
+            const DevEvent e = ldk_struct(&a.events[e_i]);
+            double num[PPL];                            // 1 / numeraire of the event: the divisions below become multiplications
+            if (e.kind != MCX_EV_EXPO_BS || e.aux[2] > 0.0) {
+                dev_atoms<PPL>(e.num, a.paths, D, ld, i, num);
+#pragma unroll
+                for (int q = 0; q < PPL; ++q) num[q] = mcx_rcp(num[q]);
+            }
+            if (e.kind <= MCX_EV_EXERCISE) {
+                double common[PPL], own[PPL], glog[PPL];
+#pragma unroll
+                for (int q = 0; q < PPL; ++q) { common[q] = 0.0; own[q] = 0.0; glog[q] = 0.0; }
+                const bool binary = e.kind == MCX_EV_OPTION && e.aux[0] == 3.0;
+                const bool basket = e.kind == MCX_EV_OPTION && e.aux[0] != 0.0 && !binary;
+                for (int j = e.term_begin; j < e.term_end; ++j) {
+                    const DevTerm tm = ldk_struct(&a.terms[j]);
+                    double av[PPL];
+                    dev_atoms<PPL>(tm.atom, a.paths, D, ld, i, av);
+                    if (tm.den < 0) {
+#pragma unroll
+                        for (int q = 0; q < PPL; ++q) common[q] = binary ? fma(tm.w, av[q], common[q]) : common[q] + tm.w * av[q];
+                    } else {
+                        double dn[PPL];
+                        dev_atoms<PPL>(ldk_struct(&a.atoms[tm.den]), a.paths, D, ld, i, dn);
+#pragma unroll
+                        for (int q = 0; q < PPL; ++q) own[q] += tm.w * av[q] / dn[q];
+                    }
+                    if (basket) {
+#pragma unroll
+                        for (int q = 0; q < PPL; ++q) glog[q] = fma(tm.w, mcx_log(av[q] + 1e-10), glog[q]);
+                    }
+                }
+                double v[PPL];
+                if (e.kind == MCX_EV_CASHFLOW) {
+#pragma unroll
+                    for (int q = 0; q < PPL; ++q) v[q] = common[q] * num[q] + own[q];
+                } else if (binary) {
+#pragma unroll
+                    for (int q = 0; q < PPL; ++q) {
+                        const double dot = fmin(fmax((common[q] - e.strike + e.aux[2]) / (2.0 * e.aux[2]), 0.0), 1.0);
+                        v[q] = e.aux[1] * (e.sign > 0.0 ? dot : 1.0 - dot) * num[q];
+                    }
+                } else {
+                    double imm[PPL];
+#pragma unroll
+                    for (int q = 0; q < PPL; ++q) imm[q] = fmax(e.sign * (common[q] - e.strike), 0.0);
+                    if (basket) {
+#pragma unroll
+                        for (int q = 0; q < PPL; ++q) {
+                            const double geo = fmax(e.sign * (mcx_exp(glog[q]) - e.strike), 0.0);
+                            v[q] = (e.aux[0] == 1.0 ? geo : imm[q] - geo + e.aux[1]) * num[q];
+                        }
+                    } else if (e.kind == MCX_EV_OPTION) {
+#pragma unroll
+                        for (int q = 0; q < PPL; ++q) v[q] = imm[q] * num[q];
+                    } else {                                   // MCX_EV_EXERCISE (bermudan_option.py:93-131, flexicall.py:118-133)
+                        double x[PPL];
+                        if (e.coeff_off >= 0) dev_atoms<PPL>(e.x, a.paths, D, ld, i, x);
+#pragma unroll
+                        for (int q = 0; q < PPL; ++q) {
+                            double cont = 0.0, cont_ex = 0.0;
+                            if (e.coeff_off >= 0) {
+                                cont = dev_poly(a.coeffs + e.coeff_off + s[q] * K, K, x[q]);
+                                if (e.aux[0] == 1.0 && s[q] > 0) cont_ex = dev_poly(a.coeffs + e.coeff_off + (s[q] - 1) * K, K, x[q]);
+                            }
+                            const bool ex = dev_exercise_decision((imm[q] + cont_ex > cont) && (s[q] > 0), s[q], a.ex_mode,
+                                                                  a.ex_mode ? a.ex_bits + (int64_t)e_i * a.ex_ld + i[q] : nullptr, 0);
+                            if (ex) s[q] -= 1;
+                            v[q] = ex ? imm[q] * num[q] : 0.0;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < PPL; ++q) acc[q] += v[q];
+            } else {
+                double v[PPL];
+#pragma unroll
+                for (int q = 0; q < PPL; ++q) v[q] = 0.0;
+                if (e.kind == MCX_EV_EXPO_POLY) {
+                    double x[PPL];
+                    dev_atoms<PPL>(e.x, a.paths, D, ld, i, x);
+#pragma unroll
+                    for (int q = 0; q < PPL; ++q) v[q] = 0.0;
+                    if (e.coeff_off >= 0) {
+                        if (pr.n_states == 1) {                // stateless product: one coefficient row for every lane -> scalar loads
+                            const double* __restrict__ c = a.coeffs + e.coeff_off + pr.init_state * K;
+                            double xp[PPL];
+#pragma unroll
+                            for (int q = 0; q < PPL; ++q) xp[q] = 1.0;
+                            for (int k = 0; k < K; ++k) {
+                                const double ck = ldk(c + k);
+#pragma unroll
+                                for (int q = 0; q < PPL; ++q) { v[q] = fma(ck, xp[q], v[q]); xp[q] *= x[q]; }
+                            }
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < PPL; ++q) v[q] = dev_poly(a.coeffs + e.coeff_off + s[q] * K, K, x[q]);
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < PPL; ++q) v[q] *= num[q];
+                } else if (e.aux[2] > 0.0) {                  // MCX_EV_EXPO_BS (european_option.py:88-145)
+                    double spot[PPL];
+                    dev_atoms<PPL>(e.x, a.paths, D, ld, i, spot);
+                    const double sig = e.aux[0], rate = e.aux[1], tau = e.aux[2], Kx = e.strike;
+                    const double sq = sqrt(tau), df = exp(-rate * tau);
+#pragma unroll
+                    for (int q = 0; q < PPL; ++q) {
+                        const double d1 = (log(spot[q] / Kx) + (rate + 0.5 * sig * sig) * tau) / (sig * sq);
+                        const double d2 = d1 - sig * sq;
+                        const double price = e.sign > 0.0 ? spot[q] * dev_norm_cdf(d1) - Kx * df * dev_norm_cdf(d2)
+                                                          : Kx * df * dev_norm_cdf(-d2) - spot[q] * dev_norm_cdf(-d1);
+                        v[q] = price * num[q];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < PPL; ++q) {
+                    if (!live[q]) continue;
+                    double* dst = a.expo + ((int64_t)pr.netting_set * a.n_expo_rows + e.row) * a.ld_out + i[q];
+                    if (e.flags & 1) *dst += v[q];
+                    else *dst = v[q];
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) acc_ns[q] += acc[q];
+    }
+    if (cur_ns >= 0 && a.want_cfs) {
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) if (live[q]) a.cfs[(int64_t)cur_ns * a.ld_out + i[q]] = acc_ns[q];
+    }
+}
+
 // out[j] = sum over chunks of part[c][j] in chunk order (deterministic)
 __global__ __launch_bounds__(MCX_BLOCK) void k2_sum_chunks(const double* __restrict__ part, int n_chunks, int64_t count, double* __restrict__ out)
 {
@@ -207,6 +393,18 @@ extern "C" int mcx_eval_book(mcx_handle* h, const mcx_book* b, const double* d_p
         if (n_chunks < 2) n_chunks = 1;
     }
     if (n_chunks == 1) {
+        bool barrier = false;
+        for (const DevEvent& e : b->h_events) barrier = barrier || (e.kind == MCX_EV_OPTION && (e.aux[0] == 4.0 || e.aux[0] == 5.0));
+#ifndef MCX_K2_PPL
+#define MCX_K2_PPL 2
+#endif
+        constexpr int PPL = MCX_K2_PPL;
+        if (!barrier && grid >= 8 * h->n_cu) {          // enough paths to fill the chip at PPL paths per lane
+            const int gv = (int)((n_paths + (int64_t)MCX_BLOCK * PPL - 1) / ((int64_t)MCX_BLOCK * PPL));
+            hipLaunchKernelGGL((k2_eval_book_v<PPL>), dim3(gv), dim3(MCX_BLOCK), 0, s, a);
+            MCX_HIP(h, hipGetLastError());
+            return 0;
+        }
         hipLaunchKernelGGL(k2_eval_book, dim3(grid), dim3(MCX_BLOCK), 0, s, a);
         MCX_HIP(h, hipGetLastError());
         return 0;

@@ -104,6 +104,16 @@ __device__ __forceinline__ void mcx_sincos2pi(double u, double& s, double& c)
     c = ((q + 1) & 2) ? -b : b;
 }
 
+// 1 / d for a normal d (numeraires, annuities): v_rcp_f64 seed + two Newton steps, no IEEE fix-up paths (a full f64 division
+// compiles to ~14 VALU instructions: div_scale x2, rcp, five fma, div_fmas, div_fixup).  <= 1 ulp
+__device__ __forceinline__ double mcx_rcp(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+}
+
 // sqrt(a) for a >= 0 in the normal range (Box-Muller radius^2, CIR state): v_rsq_f64 seed (~2^-26) + one coupled
 // Goldschmidt step (~2^-50) + one residual correction, without the scaling / special-case code of the IEEE-complete library
 // routine.  <= 1 ulp (correctly rounded in ~99.9 % of cases; a second residual step changed no path beyond 1e-15).

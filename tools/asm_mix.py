@@ -21,7 +21,7 @@ def main():
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=on", "-DMCX_LEAN_ONE_SIG",
                                "--cuda-device-only", "-S", "kf_lean.hip", "-o", out], cwd=CS, stderr=subprocess.DEVNULL)
         text = open(out).read()
-    m = re.search(r"^(_ZN\S*kf_leanILi2ELi2ELb0ELi1ELi2E[^\s:]*):[^\n]*\n(.*?)\.end_amdhsa_kernel", text, flags=re.S | re.M)
+    m = re.search(r"^(_ZN\S*kf_leanILi2ELi2ELb0ELi1ELi2ELb1E[^\s:]*):[^\n]*\n(.*?)\.end_amdhsa_kernel", text, flags=re.S | re.M)
     lines = m.group(2).split("\n")
     # innermost loop with v_mad_u64_u32: label .LBBx_y ... s_cbranch* .LBBx_y
     best = None

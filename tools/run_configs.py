@@ -111,5 +111,6 @@ if __name__ == "__main__":
     be = _native.HipBackend(0)
     which = [int(a) for a in sys.argv[1:]] or [2, 3, 4, 5, 6]
     for c in which:
+        torch.cuda.empty_cache()        # each configuration starts from an empty caching allocator (no blocks split by the previous one)
         r = {2: config2, 3: config3, 4: config4, 5: config5, 6: config3_aad}[c](be)
         print(json.dumps(r, default=float), flush=True)
