@@ -56,6 +56,8 @@ struct FastDate {
     // flag 256: the exposure polynomial's coefficient row is indexed by the lane's exercise state (coeff_off0 + state * n_basis)
     int32_t ex_n, ex_term_off, ex_coeff_off, ex_x_reg, ex_lin_reg, ex_pad;
     double ex_k0, ex_k1, ex_strike, ex_sign, ex_x_a, ex_x_d;
+    // flag 512: the date's cash value is a plain option payoff (european_option.py:45-68): max(op_sign (value - op_strike), 0)
+    double op_strike, op_sign;
 };
 struct LeanTerm { double w, c0, c1; int32_t reg, pad; };     // w exp(c0 + c1 reg[reg]), read through scalar loads
 

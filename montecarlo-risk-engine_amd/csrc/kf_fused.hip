@@ -566,8 +566,16 @@ extern "C" int mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_boo
             if (!okf) break;
             const bool stateful = e.sidx >= 0;
             if (stateful && (e.sidx != 0 || e.pad != 2 || d->n_netting_sets != 1)) { okf = false; break; }      // one two-state product
-            if (e.kind != MCX_EV_CASHFLOW && e.kind != MCX_EV_EXPO_POLY && !(e.kind == MCX_EV_EXERCISE && stateful && e.aux[0] == 0.0)) { okf = false; break; }
+            const bool plain_option = e.kind == MCX_EV_OPTION && e.aux[0] == 0.0 && !stateful;
+            if (e.kind != MCX_EV_CASHFLOW && e.kind != MCX_EV_EXPO_POLY && !plain_option &&
+                !(e.kind == MCX_EV_EXERCISE && stateful && e.aux[0] == 0.0)) { okf = false; break; }
             if (stateful && e.kind == MCX_EV_CASHFLOW) { okf = false; break; }
+            if ((plain_option || e.kind == MCX_EV_CASHFLOW) && (fd.flags & 512)) { okf = false; break; }      // the payoff's max() stands alone
+            if (plain_option) {
+                if (fd.flags & 1) { okf = false; break; }
+                fd.flags |= 512; lean_only = true;
+                fd.op_strike = e.strike; fd.op_sign = e.sign;
+            }
             if (num && memcmp(num, &e.num, sizeof(FAtom)) != 0) { okf = false; break; }     // one numeraire per date
             num = &e.num;
             if (e.kind == MCX_EV_EXERCISE) {
@@ -590,7 +598,7 @@ extern "C" int mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_boo
                 fd.ex_n = (int32_t)lterms.size() - fd.ex_term_off;
                 continue;
             }
-            if (e.kind == MCX_EV_CASHFLOW) {
+            if (e.kind == MCX_EV_CASHFLOW || plain_option) {
                 fd.flags |= 1;
                 for (int j = e.term_begin; j < e.term_end && okf; ++j) {
                     const FTerm& tm = terms_by_date[t][j];

@@ -131,6 +131,11 @@ __device__ __forceinline__ void lean_date(int t, const int64_t (&i)[PPL], const 
 #pragma unroll
             for (int q = 0; q < PPL; ++q) val[q] = fma(w, mcx_exp_tab(fma(c1, reg[q][r], c0), etab, ec), val[q]);
         }
+        if (flags & 512) {                                 // plain option payoff (european_option.py:45-68)
+            const double strike = FD(op_strike), sign = FD(op_sign);
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) val[q] = fmax(sign * (val[q] - strike), 0.0);
+        }
 #pragma unroll
         for (int q = 0; q < PPL; ++q) cfs[q] = fma(val[q], inv[q], cfs[q]);
     }
@@ -382,7 +387,12 @@ __global__ __launch_bounds__(MCX_BLOCK, MCX_LEAN_WAVES) void kf_lean(const Fused
 template <int NSLOT, int NZ, int SIG>
 void launch_lean(const FusedArgs& a, int n_cu, bool inject, bool simulate, hipStream_t s, int* grid_out)
 {
-    constexpr int PPL = MCX_LEAN_PPL;
+    // two paths per lane where both fit the 128-VGPR budget of 4 waves per SIMD; the generic (run-time model dispatch) kernels of
+    // several sub-models carry every model's step code and would spill (3 slots: 1.2 KB of scratch per lane): one path per lane
+#ifndef MCX_LEAN_PPL_HESTON
+#define MCX_LEAN_PPL_HESTON MCX_LEAN_PPL
+#endif
+    constexpr int PPL = (SIG == SIG_GENERIC && NSLOT >= 2) ? 1 : (SIG == SIG_HESTON_QE ? MCX_LEAN_PPL_HESTON : MCX_LEAN_PPL);
     const int64_t tiles = (a.k1.n + MCX_BLOCK * PPL - 1) / (MCX_BLOCK * PPL);
     const int64_t resident = (int64_t)MCX_LEAN_WAVES * n_cu;    // __launch_bounds__(256, 4): 4 blocks per CU, all co-resident
     int grid = (int)tiles;

@@ -218,8 +218,10 @@ __device__ __forceinline__ void step_slot(const SL& sl, int scheme_rt, int flags
     case MCX_MODEL_HESTON: {
         const double logS = s0, v = s1;
         const double sigma = p[1], rate = p[2], kappa = p[4], theta = p[5];
+        // (roots and reciprocals: v_rsq_f64 / v_rcp_f64 seeds + Newton steps, <= 1 ulp, instead of the IEEE-complete library
+        //  sqrt and division sequences — five roots and six divisions per QE step were ~170 of its ~270 f64 instructions)
         if (scheme == MCX_SCHEME_EULER) {                                 // heston.py:109-121
-            const double sv = sqrt(fmax(v, 0.0));
+            const double sv = mcx_sqrt(fmax(v, 0.0));
             s0 = logS + (rate - 0.5 * v) * dt + sv * sq * zc0;
             s1 = fmax(v + kappa * (theta - v) * dt + sigma * sv * sq * zc1, 0.0);
         } else {                                                          // heston.py:161-253 (Andersen QE)
@@ -227,23 +229,23 @@ __device__ __forceinline__ void step_slot(const SL& sl, int scheme_rt, int flags
             const bool fuzzy = (flags & MCX_FLAG_SMOOTHING) != 0;
             const double m = theta + (v - theta) * ldk(aux + 0);
             const double s2 = v * ldk(aux + 6) + ldk(aux + 7);
-            const double psi = s2 / (m * m + eps);
-            const double invpsi = 1.0 / (psi + eps);
+            const double psi = s2 * mcx_rcp(m * m + eps);
+            const double invpsi = mcx_rcp(psi + eps);
             const double t = fmax(2.0 * invpsi - 1.0, 0.0);
-            const double b2 = fmax(2.0 * invpsi - 1.0 + sqrt(2.0 * invpsi) * sqrt(t), 0.0);
-            const double b = sqrt(b2);
-            const double a = m / (1.0 + b2);
+            const double b2 = fmax(2.0 * invpsi - 1.0 + mcx_sqrt(2.0 * invpsi) * mcx_sqrt(t), 0.0);
+            const double b = mcx_sqrt(b2);
+            const double a = m * mcx_rcp(1.0 + b2);
             const double v1 = a * (b + zc1) * (b + zc1);
-            const double pp = fmin(fmax((psi - 1.0) / (psi + 1.0), 0.0), 1.0 - 1e-6);
-            const double beta = (1.0 - pp) / (m + eps);
+            const double pp = fmin(fmax((psi - 1.0) * mcx_rcp(psi + 1.0), 0.0), 1.0 - 1e-6);
+            const double beta = (1.0 - pp) * mcx_rcp(m + eps);
             const double omu = fmax(1.0 - u, eps);
             const double omp = fmax(1.0 - pp, eps);
-            const double v_tail = mcx_log(omp / omu) / (beta + eps);
+            const double v_tail = mcx_log(omp * mcx_rcp(omu)) * mcx_rcp(beta + eps);
             const double v2 = degree_of_truth(u - pp, fuzzy, 0.3) * v_tail;
             const double w = degree_of_truth(psi - 1.5, fuzzy, 0.5);
             const double vn = (1.0 - w) * v1 + w * v2;
             const double var_int = fmax(ldk(aux + 4) * v + ldk(aux + 5) * vn, 0.0);
-            const double vol = sqrt(fmax(var_int, eps));
+            const double vol = mcx_sqrt(fmax(var_int, eps));
             s0 = logS + rate * dt + ldk(aux + 1) + ldk(aux + 2) * v + ldk(aux + 3) * vn + vol * zc0;
             s1 = vn;
         }
