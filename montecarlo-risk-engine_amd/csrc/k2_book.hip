@@ -158,21 +158,10 @@ __global__ __launch_bounds__(MCX_BLOCK) void k2_eval_book(const K2Args a)
 // scalar record loads and dependent 8-byte global loads with 4 resident waves per SIMD.  Here a lane carries PPL paths through
 // the same (wave-uniform) program: PPL independent loads in flight per event, every record load and branch paid once per
 // PPL x 64 paths.  Books with barrier events (per-path bridge RNG) and the product-chunked mode stay on the kernel above.
-template <int PPL>
-__device__ __forceinline__ void dev_atoms(const DevAtom& a, const double* __restrict__ paths, int64_t D, int64_t ld, const int64_t (&i)[PPL],
-                                          double (&v)[PPL])
-{
-    double x[PPL];
-#pragma unroll
-    for (int q = 0; q < PPL; ++q) x[q] = a.col >= 0 ? paths[((int64_t)a.t_idx * D + a.col) * ld + i[q]] : 0.0;
-#pragma unroll
-    for (int q = 0; q < PPL; ++q) {
-        v[q] = fma(a.d, x[q], a.a);
-        if (a.b != 0.0) v[q] = fma(a.b, mcx_exp(fma(a.c1, x[q], a.c0)), v[q]);
-    }
-}
-
-template <int PPL>
+// FEAT: the event families the book contains (host-side scan); everything else compiles out, which is what keeps the common
+// books (cashflows, plain options, polynomial exposures) at 8 resident waves per SIMD.
+enum { K2F_DEN = 1, K2F_EXOTIC = 2, K2F_EXERCISE = 4, K2F_BS_EXPO = 8, K2F_ALL = 15 };
+template <int PPL, int FEAT>
 __global__ __launch_bounds__(MCX_BLOCK) void k2_eval_book_v(const K2Args a)
 {
     int64_t i[PPL];
@@ -183,7 +172,11 @@ __global__ __launch_bounds__(MCX_BLOCK) void k2_eval_book_v(const K2Args a)
         live[q] = i_raw < a.n;
         i[q] = live[q] ? i_raw : a.n - 1;
     }
+    __shared__ double etab[MCX_EXP_LDS_DOUBLES];         // 2^(j/128): the exponentials of the atoms (mcx_exp_tab)
+    mcx_exp_tab_load(etab);
+    __syncthreads();
     if (!live[0]) return;
+    const mcx_expq_coef ec = mcx_expq_load();
     const int64_t D = a.n_state, ld = a.ld;
     const int K = a.n_basis;
     int cur_ns = -1;
@@ -206,11 +199,14 @@ __global__ __launch_bounds__(MCX_BLOCK) void k2_eval_book_v(const K2Args a)
         double acc[PPL];
 #pragma unroll
         for (int q = 0; q < PPL; ++q) { s[q] = pr.init_state; acc[q] = 0.0; }
+        double num[PPL];                                // 1 / numeraire of the event: the divisions below become multiplications
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) num[q] = 0.0;
         for (int e_i = pr.ev_begin; e_i < pr.ev_end; ++e_i) {
             const DevEvent e = ldk_struct(&a.events[e_i]);
-            double num[PPL];                            // 1 / numeraire of the event: the divisions below become multiplications
-            if (e.kind != MCX_EV_EXPO_BS || e.aux[2] > 0.0) {
-                dev_atoms<PPL>(e.num, a.paths, D, ld, i, num);
+            // flags bit 1: same numeraire atom as the previous event of the product (cashflow and exposure of one date): kept
+            if (!(e.flags & 2) && (e.kind != MCX_EV_EXPO_BS || e.aux[2] > 0.0)) {
+                dev_atoms<PPL>(e.num, a.paths, D, ld, i, num, etab, ec);
 #pragma unroll
                 for (int q = 0; q < PPL; ++q) num[q] = mcx_rcp(num[q]);
             }
@@ -218,18 +214,18 @@ __global__ __launch_bounds__(MCX_BLOCK) void k2_eval_book_v(const K2Args a)
                 double common[PPL], own[PPL], glog[PPL];
 #pragma unroll
                 for (int q = 0; q < PPL; ++q) { common[q] = 0.0; own[q] = 0.0; glog[q] = 0.0; }
-                const bool binary = e.kind == MCX_EV_OPTION && e.aux[0] == 3.0;
-                const bool basket = e.kind == MCX_EV_OPTION && e.aux[0] != 0.0 && !binary;
+                const bool binary = (FEAT & K2F_EXOTIC) && e.kind == MCX_EV_OPTION && e.aux[0] == 3.0;
+                const bool basket = (FEAT & K2F_EXOTIC) && e.kind == MCX_EV_OPTION && e.aux[0] != 0.0 && !binary;
                 for (int j = e.term_begin; j < e.term_end; ++j) {
                     const DevTerm tm = ldk_struct(&a.terms[j]);
                     double av[PPL];
-                    dev_atoms<PPL>(tm.atom, a.paths, D, ld, i, av);
-                    if (tm.den < 0) {
+                    dev_atoms<PPL>(tm.atom, a.paths, D, ld, i, av, etab, ec);
+                    if (!(FEAT & K2F_DEN) || tm.den < 0) {
 #pragma unroll
                         for (int q = 0; q < PPL; ++q) common[q] = binary ? fma(tm.w, av[q], common[q]) : common[q] + tm.w * av[q];
                     } else {
                         double dn[PPL];
-                        dev_atoms<PPL>(ldk_struct(&a.atoms[tm.den]), a.paths, D, ld, i, dn);
+                        dev_atoms<PPL>(ldk_struct(&a.atoms[tm.den]), a.paths, D, ld, i, dn, etab, ec);
 #pragma unroll
                         for (int q = 0; q < PPL; ++q) own[q] += tm.w * av[q] / dn[q];
                     }
@@ -258,12 +254,12 @@ __global__ __launch_bounds__(MCX_BLOCK) void k2_eval_book_v(const K2Args a)
                             const double geo = fmax(e.sign * (mcx_exp(glog[q]) - e.strike), 0.0);
                             v[q] = (e.aux[0] == 1.0 ? geo : imm[q] - geo + e.aux[1]) * num[q];
                         }
-                    } else if (e.kind == MCX_EV_OPTION) {
+                    } else if (!(FEAT & K2F_EXERCISE) || e.kind == MCX_EV_OPTION) {
 #pragma unroll
                         for (int q = 0; q < PPL; ++q) v[q] = imm[q] * num[q];
                     } else {                                   // MCX_EV_EXERCISE (bermudan_option.py:93-131, flexicall.py:118-133)
                         double x[PPL];
-                        if (e.coeff_off >= 0) dev_atoms<PPL>(e.x, a.paths, D, ld, i, x);
+                        if (e.coeff_off >= 0) dev_atoms<PPL>(e.x, a.paths, D, ld, i, x, etab, ec);
 #pragma unroll
                         for (int q = 0; q < PPL; ++q) {
                             double cont = 0.0, cont_ex = 0.0;
@@ -286,11 +282,11 @@ __global__ __launch_bounds__(MCX_BLOCK) void k2_eval_book_v(const K2Args a)
                 for (int q = 0; q < PPL; ++q) v[q] = 0.0;
                 if (e.kind == MCX_EV_EXPO_POLY) {
                     double x[PPL];
-                    dev_atoms<PPL>(e.x, a.paths, D, ld, i, x);
+                    dev_atoms<PPL>(e.x, a.paths, D, ld, i, x, etab, ec);
 #pragma unroll
                     for (int q = 0; q < PPL; ++q) v[q] = 0.0;
                     if (e.coeff_off >= 0) {
-                        if (pr.n_states == 1) {                // stateless product: one coefficient row for every lane -> scalar loads
+                        if (!(FEAT & K2F_EXERCISE) || pr.n_states == 1) {                // stateless product: one coefficient row for every lane -> scalar loads
                             const double* __restrict__ c = a.coeffs + e.coeff_off + pr.init_state * K;
                             double xp[PPL];
 #pragma unroll
@@ -307,9 +303,9 @@ __global__ __launch_bounds__(MCX_BLOCK) void k2_eval_book_v(const K2Args a)
                     }
 #pragma unroll
                     for (int q = 0; q < PPL; ++q) v[q] *= num[q];
-                } else if (e.aux[2] > 0.0) {                  // MCX_EV_EXPO_BS (european_option.py:88-145)
+                } else if ((FEAT & K2F_BS_EXPO) && e.aux[2] > 0.0) {                  // MCX_EV_EXPO_BS (european_option.py:88-145)
                     double spot[PPL];
-                    dev_atoms<PPL>(e.x, a.paths, D, ld, i, spot);
+                    dev_atoms<PPL>(e.x, a.paths, D, ld, i, spot, etab, ec);
                     const double sig = e.aux[0], rate = e.aux[1], tau = e.aux[2], Kx = e.strike;
                     const double sq = sqrt(tau), df = exp(-rate * tau);
 #pragma unroll
@@ -401,7 +397,29 @@ extern "C" int mcx_eval_book(mcx_handle* h, const mcx_book* b, const double* d_p
         constexpr int PPL = MCX_K2_PPL;
         if (!barrier && grid >= 8 * h->n_cu) {          // enough paths to fill the chip at PPL paths per lane
             const int gv = (int)((n_paths + (int64_t)MCX_BLOCK * PPL - 1) / ((int64_t)MCX_BLOCK * PPL));
-            hipLaunchKernelGGL((k2_eval_book_v<PPL>), dim3(gv), dim3(MCX_BLOCK), 0, s, a);
+            int feat = 0;
+            for (const DevEvent& e : b->h_events) {
+                if (e.kind == MCX_EV_OPTION && e.aux[0] != 0.0) feat |= K2F_EXOTIC;
+                if (e.kind == MCX_EV_EXERCISE) feat |= K2F_EXERCISE;
+                if (e.kind == MCX_EV_EXPO_BS) feat |= K2F_BS_EXPO;
+            }
+            for (const DevProduct& pr : b->h_products) if (pr.n_states != 1) feat |= K2F_EXERCISE;
+            for (const DevTerm& tm : b->h_terms) if (tm.den >= 0) feat |= K2F_DEN;
+#ifndef MCX_K2_PPL_LIGHT
+#define MCX_K2_PPL_LIGHT 4
+#endif
+            // cashflow / plain-option / polynomial-exposure books are light on registers: more paths per lane, so that every
+            // wave of a million-path run is resident at once and the event chain is walked once per 256 paths
+            constexpr int PL = MCX_K2_PPL_LIGHT;
+            const bool wide = grid >= 4 * PL * h->n_cu;
+            const int gl = (int)((n_paths + (int64_t)MCX_BLOCK * PL - 1) / ((int64_t)MCX_BLOCK * PL));
+            if (feat == 0 && wide) hipLaunchKernelGGL((k2_eval_book_v<PL, 0>), dim3(gl), dim3(MCX_BLOCK), 0, s, a);
+            else if (feat == K2F_DEN && wide) hipLaunchKernelGGL((k2_eval_book_v<PL, K2F_DEN>), dim3(gl), dim3(MCX_BLOCK), 0, s, a);
+            else if (feat == 0) hipLaunchKernelGGL((k2_eval_book_v<PPL, 0>), dim3(gv), dim3(MCX_BLOCK), 0, s, a);
+            else if (feat == K2F_DEN) hipLaunchKernelGGL((k2_eval_book_v<PPL, K2F_DEN>), dim3(gv), dim3(MCX_BLOCK), 0, s, a);
+            else if (!(feat & (K2F_EXOTIC | K2F_BS_EXPO))) hipLaunchKernelGGL((k2_eval_book_v<PPL, K2F_DEN | K2F_EXERCISE>), dim3(gv), dim3(MCX_BLOCK), 0, s, a);
+            else if (!(feat & K2F_BS_EXPO)) hipLaunchKernelGGL((k2_eval_book_v<PPL, K2F_DEN | K2F_EXERCISE | K2F_EXOTIC>), dim3(gv), dim3(MCX_BLOCK), 0, s, a);
+            else hipLaunchKernelGGL((k2_eval_book_v<PPL, K2F_ALL>), dim3(gv), dim3(MCX_BLOCK), 0, s, a);
             MCX_HIP(h, hipGetLastError());
             return 0;
         }

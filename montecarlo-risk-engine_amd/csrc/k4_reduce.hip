@@ -76,6 +76,42 @@ __global__ __launch_bounds__(MCX_BLOCK) void k4_cva_paths(const DevUnsec u, cons
     out[i] = acc * lgd;
 }
 
+// the same with PPL paths per lane and table exponentials (large path counts: independent loads in flight, the atom records
+// and the date loop paid once per PPL x 64 paths)
+template <int PPL>
+__global__ __launch_bounds__(MCX_BLOCK) void k4_cva_paths_v(const DevUnsec u, const DevAtom* __restrict__ atoms,
+                                                            const int32_t* __restrict__ surv, const int32_t* __restrict__ cond,
+                                                            double lgd, const double* __restrict__ expo, const double* __restrict__ paths,
+                                                            int64_t D, int64_t n, int64_t ld_expo, int64_t ld_paths, double* __restrict__ out)
+{
+    __shared__ double etab[MCX_EXP_LDS_DOUBLES];
+    mcx_exp_tab_load(etab);
+    __syncthreads();
+    int64_t i[PPL];
+    bool live[PPL];
+    double acc[PPL];
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) {
+        const int64_t i_raw = ((int64_t)blockIdx.x * PPL + q) * MCX_BLOCK + threadIdx.x;
+        live[q] = i_raw < n;
+        i[q] = live[q] ? i_raw : n - 1;
+        acc[q] = 0.0;
+    }
+    if (!live[0]) return;
+    const mcx_expq_coef ec = mcx_expq_load();
+    for (int m = 0; m < u.n_dates - 1; ++m) {
+        double e[PPL], sp[PPL], cs[PPL];
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) e[q] = fmax(dev_unsec(u, expo, ld_expo, m, i[q]), 0.0);
+        dev_atoms<PPL>(ldk_struct(&atoms[ldk(surv + m)]), paths, D, ld_paths, i, sp, etab, ec);
+        dev_atoms<PPL>(ldk_struct(&atoms[ldk(cond + m)]), paths, D, ld_paths, i, cs, etab, ec);
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) acc[q] = fma(e[q], sp[q] * (1.0 - cs[q]), acc[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) if (live[q]) out[i[q]] = acc[q] * lgd;
+}
+
 __global__ __launch_bounds__(MCX_BLOCK) void k4_unsecured(const DevUnsec u, const double* __restrict__ expo, int64_t n, int64_t ld,
                                                           double* __restrict__ out, int64_t ld_out)
 {
@@ -152,8 +188,12 @@ extern "C" int mcx_reduce_cva(mcx_handle* h, const mcx_book* b, const mcx_unsecu
         if (!d_ids) return -100;
     }
     const int grid = (int)((n_paths + MCX_BLOCK - 1) / MCX_BLOCK);
-    hipLaunchKernelGGL(k4_cva_paths, dim3(grid), dim3(MCX_BLOCK), 0, s, du, b->d_atoms, d_ids, d_ids + nd, 1.0 - recovery, d_expo_ns,
-                       d_paths, (int64_t)b->n_state, n_paths, ld_expo, ld_paths, d_v);
+    if (grid >= 16 * h->n_cu)
+        hipLaunchKernelGGL((k4_cva_paths_v<2>), dim3((grid + 1) / 2), dim3(MCX_BLOCK), 0, s, du, b->d_atoms, d_ids, d_ids + nd, 1.0 - recovery,
+                           d_expo_ns, d_paths, (int64_t)b->n_state, n_paths, ld_expo, ld_paths, d_v);
+    else
+        hipLaunchKernelGGL(k4_cva_paths, dim3(grid), dim3(MCX_BLOCK), 0, s, du, b->d_atoms, d_ids, d_ids + nd, 1.0 - recovery, d_expo_ns,
+                           d_paths, (int64_t)b->n_state, n_paths, ld_expo, ld_paths, d_v);
     MCX_HIP(h, hipGetLastError());
     return reduce_vector_dev(h, d_v, n_paths, h_out, s);
 }

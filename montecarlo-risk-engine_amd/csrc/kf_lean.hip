@@ -348,14 +348,16 @@ __global__ __launch_bounds__(MCX_BLOCK, MCX_LEAN_WAVES) void kf_lean(const Fused
                     }
             };
             const int n_dates = kargs_region(0).n_dates;
+            double nx2[PPL][NREG];                     // two dates in flight: the pass is a pure stream, latency is hidden by depth
             load_row(0, nxt);
+            load_row(n_dates > 1 ? 1 : 0, nx2);
 #pragma unroll 1
             for (int t = 0; t < n_dates; ++t) {
 #pragma unroll
                 for (int q = 0; q < PPL; ++q)
 #pragma unroll
-                    for (int r = 0; r < NREG; ++r) reg[q][r] = nxt[q][r];
-                if (t + 1 < n_dates) load_row(t + 1, nxt);            // next date's state streams in while this date's program runs
+                    for (int r = 0; r < NREG; ++r) { reg[q][r] = nxt[q][r]; nxt[q][r] = nx2[q][r]; }
+                if (t + 2 < n_dates) load_row(t + 2, nx2);            // the state of date t+2 streams in while this date's program runs
                 lean_date<NSLOT, SIG, PPL, false>(t, i, live, first_tile, lds, reg, cfs, cva, est, etab);
             }
         }

@@ -149,6 +149,7 @@ extern "C" int mcx_book_create(mcx_handle* h, const mcx_book_desc* d, mcx_book**
         DevProduct& o = b->h_products[p];
         o.ev_begin = pr.ev_begin; o.ev_end = pr.ev_end; o.cf_begin = pr.cf_begin; o.cf_end = pr.cf_end;
         o.netting_set = pr.netting_set; o.init_state = pr.init_state; o.n_states = pr.n_states; o.flags = pr.flags;
+        bool have_num = false;
         for (int q = pr.ev_begin; q < pr.ev_end; ++q) {
             DevEvent& e = events[q];
             e.netting_set = pr.netting_set;
@@ -157,6 +158,11 @@ extern "C" int mcx_book_create(mcx_handle* h, const mcx_book_desc* d, mcx_book**
                 e.flags = seen ? 1 : 0;
                 seen = 1;
             }
+            // bit 1: the numeraire atom equals the one the previous event of this product evaluated (the cashflow and the exposure
+            // of one date share it): the multi-path book kernel keeps the reciprocal in registers
+            const bool evaluates = e.kind != MCX_EV_EXPO_BS || e.aux[2] > 0.0;
+            if (have_num && evaluates && memcmp(&e.num, &events[q - 1].num, sizeof(DevAtom)) == 0) e.flags |= 2;
+            have_num = evaluates || (have_num && (e.flags & 2));
         }
     }
     b->h_events = events; b->h_events.resize(d->n_events);

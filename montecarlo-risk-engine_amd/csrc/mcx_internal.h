@@ -147,6 +147,20 @@ __device__ __forceinline__ double dev_atom(const DevAtom& a, const double* __res
     return v;
 }
 
+// PPL paths of a lane through one (wave-uniform) atom; exponentials from the block's LDS copy of the 2^(j/128) table
+template <int PPL>
+__device__ __forceinline__ void dev_atoms(const DevAtom& a, const double* __restrict__ paths, int64_t D, int64_t ld, const int64_t (&i)[PPL],
+                                          double (&v)[PPL], const double* __restrict__ etab, const mcx_expq_coef& ec)
+{
+    double x[PPL];
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) x[q] = a.col >= 0 ? paths[((int64_t)a.t_idx * D + a.col) * ld + i[q]] : 0.0;
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) {
+        v[q] = fma(a.d, x[q], a.a);
+        if (a.b != 0.0) v[q] = fma(a.b, mcx_exp_tab(fma(a.c1, x[q], a.c0), etab, ec), v[q]);
+    }
+}
 // the terms of one event mostly read the SAME state column of the SAME date (e.g. 64 zero-bond prices of one short rate):
 // keep the last (date, column) -> value in registers instead of re-issuing the global load for every term
 struct AtomCache { int t_idx, col; double x; };
