@@ -126,24 +126,29 @@ extern "C" int mcx_sim_create(mcx_handle* h, const mcx_sim_desc* d, mcx_sim** ou
     mcx_sim* sim = new mcx_sim();
     sim->desc = *d;
     sim->d_steps = nullptr; sim->d_chol = nullptr; sim->d_aux = nullptr;
-    const size_t nb_steps = sizeof(mcx_step) * (size_t)(d->n_steps > 0 ? d->n_steps : 1);
-    const size_t nb_chol = sizeof(double) * (size_t)(d->n_chol > 0 ? d->n_chol : 1) * d->n_z * d->n_z;
-    const size_t nb_aux = sizeof(double) * (size_t)(d->n_steps > 0 ? d->n_steps : 1) * d->n_slots * MCX_AUX;
-    MCX_HIP(h, hipMalloc(&sim->d_steps, nb_steps));
-    MCX_HIP(h, hipMalloc(&sim->d_chol, nb_chol));
-    MCX_HIP(h, hipMalloc(&sim->d_aux, nb_aux));
-    if (d->n_steps > 0) {
-        MCX_HIP(h, hipMemcpy(sim->d_steps, d->steps, sizeof(mcx_step) * d->n_steps, hipMemcpyHostToDevice));
-        MCX_HIP(h, hipMemcpy(sim->d_aux, d->aux, sizeof(double) * (size_t)d->n_steps * d->n_slots * MCX_AUX, hipMemcpyHostToDevice));
-    }
-    if (d->n_chol > 0)
-        MCX_HIP(h, hipMemcpy(sim->d_chol, d->chol, sizeof(double) * (size_t)d->n_chol * d->n_z * d->n_z, hipMemcpyHostToDevice));
     // init_state travels in the kernel-argument segment; keep a private host copy
     sim->n_state_total = d->n_state;
     double* init = new double[MCX_MAX_STATE]();
     for (int c = 0; c < d->n_state; ++c) init[c] = d->init_state[c];
     sim->desc.init_state = init;
+    sim->h_steps.assign(d->steps, d->steps + (d->n_steps > 0 ? d->n_steps : 0));
     sim->desc.steps = nullptr; sim->desc.chol = nullptr; sim->desc.aux = nullptr;
+    const size_t nb_steps = sizeof(mcx_step) * (size_t)(d->n_steps > 0 ? d->n_steps : 1);
+    const size_t nb_chol = sizeof(double) * (size_t)(d->n_chol > 0 ? d->n_chol : 1) * d->n_z * d->n_z;
+    const size_t nb_aux = sizeof(double) * (size_t)(d->n_steps > 0 ? d->n_steps : 1) * d->n_slots * MCX_AUX;
+    hipError_t e = hipMalloc(&sim->d_steps, nb_steps);
+    if (e == hipSuccess) e = hipMalloc(&sim->d_chol, nb_chol);
+    if (e == hipSuccess) e = hipMalloc(&sim->d_aux, nb_aux);
+    if (e == hipSuccess && d->n_steps > 0) e = hipMemcpy(sim->d_steps, d->steps, sizeof(mcx_step) * d->n_steps, hipMemcpyHostToDevice);
+    if (e == hipSuccess && d->n_steps > 0)
+        e = hipMemcpy(sim->d_aux, d->aux, sizeof(double) * (size_t)d->n_steps * d->n_slots * MCX_AUX, hipMemcpyHostToDevice);
+    if (e == hipSuccess && d->n_chol > 0)
+        e = hipMemcpy(sim->d_chol, d->chol, sizeof(double) * (size_t)d->n_chol * d->n_z * d->n_z, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {                      // nothing of a failed create survives
+        h->err = std::string("mcx_sim_create: ") + hipGetErrorString(e);
+        mcx_sim_destroy(sim);
+        return -100;
+    }
     *out = sim;
     return 0;
 }

@@ -12,8 +12,25 @@
 
 namespace {
 
+// the parameter-only factors of one QE step (heston.py:161-253): functions of (kappa, theta, sigma, rho, rate, dt), the same for
+// every path and — with an evenly spaced timeline — for every step.  Built on the host as dual numbers (value + 7 tangents),
+// one record per distinct dt; the kernel reads them with scalar loads instead of redoing ~20 dual operations per path and step.
+// Tangent order [sigma, kappa, theta, v0, rho]; the variance-chain factors carry the first four (kt_heston).
+struct QEConst {
+    Dual<4> E;        // exp(-kappa dt)
+    Dual<4> A1;       // sigma^2 E (1 - E) / kappa                  (s2 = v A1 + A2)
+    Dual<4> A2;       // theta sigma^2 (1 - E)^2 / (2 kappa)
+    Dual<5> base;     // rate dt + K0,  K0 = -(rho kappa theta / sigma) dt      (the rate tangent is the elapsed time: kt_heston)
+    Dual<5> K1;       // (kappa rho / sigma - 1/2) dt - rho / sigma      (gamma1 = 1, gamma2 = 0)
+    Dual<5> K2;       // rho / sigma
+    Dual<5> K3;       // (1 - rho^2) dt
+    double pad[3];    // 40 doubles: dword-aligned records of a power-of-two friendly size
+};
+
 struct KTArgs {
     K1Args k1;
+    const QEConst* __restrict__ qe;             // [n distinct dt]
+    const int32_t* __restrict__ qe_idx;         // [n_steps] -> record of the step's dt
     const mcx_tangent_option* __restrict__ opts;
     double* __restrict__ cfs;
     double* __restrict__ dcfs;
@@ -45,9 +62,11 @@ __global__ __launch_bounds__(MCX_BLOCK) void kt_bs(const KTArgs a)
             const double w = x > 0.0 ? 1.0 : (x == 0.0 ? 0.5 : 0.0);
             const double pay = fmax(x, 0.0);
             const double inv = 1.0 / o.numeraire;
+#pragma unroll
             for (int n = 0; n < MCX_FUSED_MAX_NS; ++n) {
                 if (n != o.netting_set) continue;
                 acc[n] += pay * inv;
+#pragma unroll
                 for (int j = 0; j < P; ++j) dacc[n][j] += w * o.sign * S.d[j] * inv;
                 dacc[n][2] -= pay * inv * inv * o.dnum_drate;
             }
@@ -70,17 +89,37 @@ __global__ __launch_bounds__(MCX_BLOCK) void kt_bs(const KTArgs a)
         }
         if (sp.store_idx >= 0) on_date(sp.store_idx);
     }
-    for (int n = 0; n < a.n_ns; ++n) {
+#pragma unroll
+    for (int n = 0; n < MCX_FUSED_MAX_NS; ++n) {          // compile-time indices: the accumulators stay in registers
+        if (n >= a.n_ns) break;
         a.cfs[(int64_t)n * a.ld_out + i] = acc[n];
+#pragma unroll
         for (int j = 0; j < P; ++j) a.dcfs[((int64_t)n * P + j) * a.ld_out + i] = dacc[n][j];
     }
 }
 
-// Heston: params [spot, sigma_v, rate, rho, kappa, theta, v0], state (log S, v)
-template <bool INJECT>
+// Heston: params [spot, sigma_v, rate, rho, kappa, theta, v0], state (log S, v).
+// The tangent sets are sparse and the kernel carries only what can be non-zero:
+//   * d logS / d spot = 1 / spot and d logS / d rate = elapsed time are constants of the path (rate and spot enter the log-price
+//     additively and the variance not at all): applied at the payoff, never propagated;
+//   * the variance depends on (sigma, kappa, theta, v0) only under QE — and on rho as well under Euler, where the variance
+//     draw is the correlated one (heston.py:109-121): PV = 4 / 5 tangents through the whole variance chain;
+//   * log S carries those and rho: PL = 5.
+// Local tangent order [sigma, kappa, theta, v0, rho].
+template <int PA, int PB>
+__device__ __forceinline__ Dual<PB> dext(const Dual<PA>& a)
+{
+    Dual<PB> r;
+    r.v = a.v;
+#pragma unroll
+    for (int j = 0; j < PB; ++j) r.d[j] = j < PA ? a.d[j] : 0.0;
+    return r;
+}
+
+template <bool INJECT, bool QE>
 __global__ __launch_bounds__(MCX_BLOCK) void kt_heston(const KTArgs a)
 {
-    constexpr int P = 7;
+    constexpr int P = 7, PV = QE ? 4 : 5, PL = 5;
     const K1Args& k = a.k1;
     const int64_t i = (int64_t)blockIdx.x * MCX_BLOCK + threadIdx.x;
     __shared__ double bm_lds[INJECT ? 2 : MCX_BM_LDS_DOUBLES];        // table-driven Box-Muller (mcx_math.h)
@@ -88,24 +127,32 @@ __global__ __launch_bounds__(MCX_BLOCK) void kt_heston(const KTArgs a)
     if (!INJECT) { mcx_bm_load(bm_lds); tab = bm_lds; }
     if (i >= k.n) return;
     const double* p = k.slots[0].p;
-    const Dual<P> spot = dseed<P>(p[0], 0), sigma = dseed<P>(p[1], 1), rate = dseed<P>(p[2], 2), rho = dseed<P>(p[3], 3),
-                  kappa = dseed<P>(p[4], 4), theta = dseed<P>(p[5], 5), v0 = dseed<P>(p[6], 6);
-    Dual<P> logS = dlog(spot), v = v0;
+    const double inv_spot = 1.0 / p[0];
+    const Dual<PV> sigma = dseed<PV>(p[1], 0), kappa = dseed<PV>(p[4], 1), theta = dseed<PV>(p[5], 2);
+    const Dual<PL> rho = dseed<PL>(p[3], 4);
+    const double rate = p[2];
+    Dual<PL> logS = dconst<PL>(mcx_log(p[0]));
+    Dual<PV> v = dseed<PV>(p[6], 3);
+    double elapsed = 0.0;                                              // d logS / d rate
     const bool fuzzy = ((k.flags | k.slots[0].flags) & MCX_FLAG_SMOOTHING) != 0;
     double acc[MCX_FUSED_MAX_NS] = {0, 0, 0, 0}, dacc[MCX_FUSED_MAX_NS][P] = {};
     auto on_date = [&](int t) {
         for (int q = 0; q < a.n_opts; ++q) {
             const mcx_tangent_option o = ldk_struct(&a.opts[q]);
             if (o.t_idx != t) continue;
-            const Dual<P> S = dexp(logS);                                          // heston.py:258-260
-            const double x = o.sign * (S.v - o.strike);
+            const double Sv = mcx_exp(logS.v);                                     // heston.py:258-260
+            // d S / d param in the reference's order [spot, sigma_v, rate, rho, kappa, theta, v0]
+            const double dS[P] = {Sv * inv_spot, Sv * logS.d[0], Sv * elapsed, Sv * logS.d[4], Sv * logS.d[1], Sv * logS.d[2], Sv * logS.d[3]};
+            const double x = o.sign * (Sv - o.strike);
             const double w = x > 0.0 ? 1.0 : (x == 0.0 ? 0.5 : 0.0);
             const double pay = fmax(x, 0.0);
             const double inv = 1.0 / o.numeraire;
+#pragma unroll
             for (int n = 0; n < MCX_FUSED_MAX_NS; ++n) {
                 if (n != o.netting_set) continue;
                 acc[n] += pay * inv;
-                for (int j = 0; j < P; ++j) dacc[n][j] += w * o.sign * S.d[j] * inv;
+#pragma unroll
+                for (int j = 0; j < P; ++j) dacc[n][j] += w * o.sign * dS[j] * inv;
                 dacc[n][2] -= pay * inv * inv * o.dnum_drate;
             }
         }
@@ -125,54 +172,84 @@ __global__ __launch_bounds__(MCX_BLOCK) void kt_heston(const KTArgs a)
             draw_pair<true>(k.seed, path, (uint32_t)step, 0u, ua, z0, z1, tab);
             if (k.n_uniform) { double t0, t1; draw_pair(k.seed, path, (uint32_t)step, 1u, u, t0, t1); }
         }
-        if (k.scheme == MCX_SCHEME_EULER) {
+        if constexpr (!QE) {
             // corr = chol([[1,rho],[rho,1]]): zc0 = z0, zc1 = rho z0 + sqrt(1-rho^2) z1      heston.py:109-121
-            const Dual<P> zc1 = rho * z0 + dsqrt(1.0 - rho * rho) * z1;
-            const Dual<P> sv = dsqrt(dclamp_min(v, 0.0));
-            const Dual<P> logS_n = logS + (rate - v * 0.5) * dt + sv * (sp.sqrt_dt * z0);
-            const Dual<P> v_n = v + kappa * (theta - v) * dt + sigma * sv * zc1 * sp.sqrt_dt;
-            logS = logS_n;
+            const Dual<PL> zc1 = rho * z0 + dsqrt(1.0 - rho * rho) * z1;
+            const Dual<PV> sv = dsqrt(dclamp_min(v, 0.0));
+            logS = logS + (rate - v * 0.5) * dt + sv * (sp.sqrt_dt * z0);
+            const Dual<PV> v_n = v + kappa * (theta - v) * dt + sigma * sv * zc1 * sp.sqrt_dt;
             v = dclamp_min(v_n, 0.0);
         } else {
-            // Andersen QE, heston.py:161-253 (same operation order as the oracle)
+            // Andersen QE, heston.py:161-253 (same operation order as the oracle); the parameter-only factors come from QEConst
             const double eps = 1e-12;
-            const Dual<P> E = dexp(kappa * (-dt));
-            const Dual<P> m = theta + (v - theta) * E;
-            const Dual<P> om = 1.0 - E;
-            const Dual<P> s2 = v * sigma * sigma * E * om / kappa + theta * sigma * sigma * om * om / (kappa * 2.0);
-            const Dual<P> psi = s2 / (m * m + eps);
-            const Dual<P> invpsi = 1.0 / (psi + eps);
-            const Dual<P> t = dclamp_min(invpsi * 2.0 - 1.0, 0.0);
-            const Dual<P> b2 = dclamp_min(invpsi * 2.0 - 1.0 + dsqrt(invpsi * 2.0) * dsqrt(t), 0.0);
-            const Dual<P> b = dsqrt(b2);
-            const Dual<P> aa = m / (1.0 + b2);
-            const Dual<P> bz = b + z1;
-            const Dual<P> v1 = aa * bz * bz;
-            const Dual<P> pp = dclamp((psi - 1.0) / (psi + 1.0), 0.0, 1.0 - 1e-6);
-            const Dual<P> beta = (1.0 - pp) / (m + eps);
+            const QEConst* qc = a.qe + ldk(a.qe_idx + step);
+            const Dual<PV> E = ldk_struct(&qc->E);
+            const Dual<PV> m = theta + (v - theta) * E;
+            const Dual<PV> s2 = v * ldk_struct(&qc->A1) + ldk_struct(&qc->A2);
+            const Dual<PV> psi = s2 / (m * m + eps);
+            const Dual<PV> invpsi = 1.0 / (psi + eps);
+            const Dual<PV> t = dclamp_min(invpsi * 2.0 - 1.0, 0.0);
+            const Dual<PV> b2 = dclamp_min(invpsi * 2.0 - 1.0 + dsqrt(invpsi * 2.0) * dsqrt(t), 0.0);
+            const Dual<PV> b = dsqrt(b2);
+            const Dual<PV> aa = m / (1.0 + b2);
+            const Dual<PV> bz = b + z1;
+            const Dual<PV> v1 = aa * bz * bz;
+            const Dual<PV> pp = dclamp((psi - 1.0) / (psi + 1.0), 0.0, 1.0 - 1e-6);
+            const Dual<PV> beta = (1.0 - pp) / (m + eps);
             const double omu = fmax(1.0 - u, eps);
-            const Dual<P> omp = dclamp_min(1.0 - pp, eps);
-            const Dual<P> v_tail = dlog(omp * (1.0 / omu)) / (beta + eps);
-            const Dual<P> w_mass = ddegree(u - pp, fuzzy, 0.3);
-            const Dual<P> v2 = w_mass * v_tail;
-            const Dual<P> w = ddegree(psi - 1.5, fuzzy, 0.5);
-            const Dual<P> vn = (1.0 - w) * v1 + w * v2;
-            const Dual<P> ros = rho / sigma;
-            const Dual<P> K0 = (rho * kappa * theta / sigma) * (-dt);
-            const Dual<P> K1 = (kappa * ros - 0.5) * dt - ros;
-            const Dual<P> K2 = ros;                                         // gamma2 = 0
-            const Dual<P> K3 = (1.0 - rho * rho) * dt;
-            const Dual<P> var_int = dclamp_min(K3 * v, 0.0);                // K4 = 0
-            const Dual<P> vol = dsqrt(dclamp_min(var_int, eps));
-            logS = logS + rate * dt + K0 + K1 * v + K2 * vn + vol * z0;
+            const Dual<PV> omp = dclamp_min(1.0 - pp, eps);
+            const Dual<PV> v_tail = dlog(omp * (1.0 / omu)) / (beta + eps);
+            const Dual<PV> w_mass = ddegree(u - pp, fuzzy, 0.3);
+            const Dual<PV> v2 = w_mass * v_tail;
+            const Dual<PV> w = ddegree(psi - 1.5, fuzzy, 0.5);
+            const Dual<PV> vn = (1.0 - w) * v1 + w * v2;
+            const Dual<PL> vL = dext<PV, PL>(v), vnL = dext<PV, PL>(vn);
+            const Dual<PL> var_int = dclamp_min(ldk_struct(&qc->K3) * vL, 0.0);               // K4 = 0
+            const Dual<PL> vol = dsqrt(dclamp_min(var_int, eps));
+            logS = logS + ldk_struct(&qc->base) + ldk_struct(&qc->K1) * vL + ldk_struct(&qc->K2) * vnL + vol * z0;
             v = vn;
         }
+        elapsed += dt;
         if (sp.store_idx >= 0) on_date(sp.store_idx);
     }
-    for (int n = 0; n < a.n_ns; ++n) {
+#pragma unroll
+    for (int n = 0; n < MCX_FUSED_MAX_NS; ++n) {          // compile-time indices: the accumulators stay in registers
+        if (n >= a.n_ns) break;
         a.cfs[(int64_t)n * a.ld_out + i] = acc[n];
+#pragma unroll
         for (int j = 0; j < P; ++j) a.dcfs[((int64_t)n * P + j) * a.ld_out + i] = dacc[n][j];
     }
+}
+
+// host-side dual numbers for the QE records (same formulas as the step they replace)
+struct HD { double v, d[5]; };        // [sigma, kappa, theta, v0, rho]
+static HD hd_c(double c) { HD r; r.v = c; for (double& x : r.d) x = 0.0; return r; }
+static HD hd_seed(double c, int k) { HD r = hd_c(c); r.d[k] = 1.0; return r; }
+static HD operator+(const HD& a, const HD& b) { HD r; r.v = a.v + b.v; for (int j = 0; j < 5; ++j) r.d[j] = a.d[j] + b.d[j]; return r; }
+static HD operator-(const HD& a, const HD& b) { HD r; r.v = a.v - b.v; for (int j = 0; j < 5; ++j) r.d[j] = a.d[j] - b.d[j]; return r; }
+static HD operator*(const HD& a, const HD& b) { HD r; r.v = a.v * b.v; for (int j = 0; j < 5; ++j) r.d[j] = a.d[j] * b.v + a.v * b.d[j]; return r; }
+static HD operator/(const HD& a, const HD& b) { HD r; const double ib = 1.0 / b.v; r.v = a.v * ib; for (int j = 0; j < 5; ++j) r.d[j] = (a.d[j] - r.v * b.d[j]) * ib; return r; }
+static HD operator*(const HD& a, double c) { return a * hd_c(c); }
+static HD hd_exp(const HD& a) { HD r; r.v = exp(a.v); for (int j = 0; j < 5; ++j) r.d[j] = r.v * a.d[j]; return r; }
+template <int PD> static void hd_store(const HD& a, Dual<PD>* out) { out->v = a.v; for (int j = 0; j < PD; ++j) out->d[j] = a.d[j]; }
+
+static QEConst qe_const(const double* p, double dt)
+{
+    // params [spot, sigma_v, rate, rho, kappa, theta, v0]
+    const HD sigma = hd_seed(p[1], 0), kappa = hd_seed(p[4], 1), theta = hd_seed(p[5], 2), rho = hd_seed(p[3], 4), rate = hd_c(p[2]);
+    const HD E = hd_exp(kappa * (-dt));
+    const HD om = hd_c(1.0) - E;
+    const HD ros = rho / sigma;
+    QEConst c;
+    memset(&c, 0, sizeof(c));
+    hd_store(E, &c.E);
+    hd_store(sigma * sigma * E * om / kappa, &c.A1);
+    hd_store(theta * sigma * sigma * om * om / (kappa * 2.0), &c.A2);
+    hd_store(rate * dt + (rho * kappa * theta / sigma) * (-dt), &c.base);
+    hd_store((kappa * ros - hd_c(0.5)) * dt - ros, &c.K1);
+    hd_store(ros, &c.K2);
+    hd_store((hd_c(1.0) - rho * rho) * dt, &c.K3);
+    return c;
 }
 
 }  // namespace
@@ -195,25 +272,43 @@ extern "C" int mcx_tangent_european(mcx_handle* h, const mcx_sim* sim, const mcx
     if (ld_out < n_paths || (d_inject_z && ld < n_paths)) MCX_FAIL(h, -2, "mcx_tangent_european: leading dimension < n_paths");
     if (d.n_uniform && d_inject_z && !d_inject_u) MCX_FAIL(h, -3, "mcx_tangent_european: inject_u required with inject_z under QE");
     hipStream_t s = (hipStream_t)stream;
-    mcx_tangent_option* d_opts = nullptr;
-    MCX_HIP(h, hipMalloc(&d_opts, sizeof(mcx_tangent_option) * (size_t)n_opts));
-    MCX_HIP(h, hipMemcpyAsync(d_opts, h_opts, sizeof(mcx_tangent_option) * (size_t)n_opts, hipMemcpyHostToDevice, s));
-    MCX_HIP(h, hipStreamSynchronize(s));
+    const mcx_tangent_option* d_opts = (const mcx_tangent_option*)mcx_stage_small(h, h_opts, sizeof(mcx_tangent_option) * (size_t)n_opts, s);
+    if (!d_opts) return -100;
     KTArgs a;
     memset(&a, 0, sizeof(a));
     mcx_fill_k1_args(sim, seed, path_offset, n_paths, ld > 0 ? ld : n_paths, nullptr, d_inject_z, d_inject_u, &a.k1);
     a.opts = d_opts; a.cfs = d_cfs; a.dcfs = d_dcfs; a.ld_out = ld_out; a.n_opts = n_opts; a.n_ns = n_netting_sets;
+    if (d.slots[0].kind == MCX_MODEL_HESTON && d.scheme == MCX_SCHEME_QE) {
+        // one record of parameter-only dual factors per distinct dt of the sub-step table
+        std::vector<double> dts;
+        std::vector<int32_t> idx(sim->h_steps.size());
+        for (size_t k = 0; k < sim->h_steps.size(); ++k) {
+            size_t q = 0;
+            while (q < dts.size() && dts[q] != sim->h_steps[k].dt) ++q;
+            if (q == dts.size()) {
+                if (dts.size() >= 4096) MCX_FAIL(h, -2, "mcx_tangent_european: more than 4096 distinct step sizes");
+                dts.push_back(sim->h_steps[k].dt);
+            }
+            idx[k] = (int32_t)q;
+        }
+        std::vector<QEConst> recs(dts.size());
+        for (size_t q = 0; q < dts.size(); ++q) recs[q] = qe_const(d.slots[0].p, dts[q]);
+        a.qe = (const QEConst*)mcx_stage_small(h, recs.data(), sizeof(QEConst) * recs.size(), s);
+        a.qe_idx = (const int32_t*)mcx_stage_small(h, idx.data(), sizeof(int32_t) * idx.size(), s);
+        if (!a.qe || !a.qe_idx) return -100;
+    }
     const int grid = (int)((n_paths + MCX_BLOCK - 1) / MCX_BLOCK);
     const bool inj = d_inject_z != nullptr;
     if (d.slots[0].kind == MCX_MODEL_BS) {
         if (inj) hipLaunchKernelGGL(kt_bs<true>, dim3(grid), dim3(MCX_BLOCK), 0, s, a);
         else hipLaunchKernelGGL(kt_bs<false>, dim3(grid), dim3(MCX_BLOCK), 0, s, a);
     } else {
-        if (inj) hipLaunchKernelGGL(kt_heston<true>, dim3(grid), dim3(MCX_BLOCK), 0, s, a);
-        else hipLaunchKernelGGL(kt_heston<false>, dim3(grid), dim3(MCX_BLOCK), 0, s, a);
+        const bool qe = d.scheme == MCX_SCHEME_QE;
+        if (qe && inj) hipLaunchKernelGGL((kt_heston<true, true>), dim3(grid), dim3(MCX_BLOCK), 0, s, a);
+        else if (qe) hipLaunchKernelGGL((kt_heston<false, true>), dim3(grid), dim3(MCX_BLOCK), 0, s, a);
+        else if (inj) hipLaunchKernelGGL((kt_heston<true, false>), dim3(grid), dim3(MCX_BLOCK), 0, s, a);
+        else hipLaunchKernelGGL((kt_heston<false, false>), dim3(grid), dim3(MCX_BLOCK), 0, s, a);
     }
     MCX_HIP(h, hipGetLastError());
-    MCX_HIP(h, hipStreamSynchronize(s));
-    MCX_HIP(h, hipFree(d_opts));
-    return 0;
+    return 0;          // stream-ordered (descriptors travel through the handle's staging ring)
 }

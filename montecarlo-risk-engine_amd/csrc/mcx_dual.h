@@ -16,7 +16,7 @@ template <int P> __device__ __forceinline__ Dual<P> dseed(double c, int k) { Dua
 template <int P> __device__ __forceinline__ Dual<P> operator+(const Dual<P>& a, const Dual<P>& b) { Dual<P> r; r.v = a.v + b.v; for (int j = 0; j < P; ++j) r.d[j] = a.d[j] + b.d[j]; return r; }
 template <int P> __device__ __forceinline__ Dual<P> operator-(const Dual<P>& a, const Dual<P>& b) { Dual<P> r; r.v = a.v - b.v; for (int j = 0; j < P; ++j) r.d[j] = a.d[j] - b.d[j]; return r; }
 template <int P> __device__ __forceinline__ Dual<P> operator*(const Dual<P>& a, const Dual<P>& b) { Dual<P> r; r.v = a.v * b.v; for (int j = 0; j < P; ++j) r.d[j] = a.d[j] * b.v + a.v * b.d[j]; return r; }
-template <int P> __device__ __forceinline__ Dual<P> operator/(const Dual<P>& a, const Dual<P>& b) { Dual<P> r; const double ib = 1.0 / b.v; r.v = a.v * ib; for (int j = 0; j < P; ++j) r.d[j] = (a.d[j] - r.v * b.d[j]) * ib; return r; }
+template <int P> __device__ __forceinline__ Dual<P> operator/(const Dual<P>& a, const Dual<P>& b) { Dual<P> r; const double ib = mcx_rcp(b.v); r.v = a.v * ib; for (int j = 0; j < P; ++j) r.d[j] = (a.d[j] - r.v * b.d[j]) * ib; return r; }
 template <int P> __device__ __forceinline__ Dual<P> operator+(const Dual<P>& a, double c) { Dual<P> r = a; r.v += c; return r; }
 template <int P> __device__ __forceinline__ Dual<P> operator-(const Dual<P>& a, double c) { Dual<P> r = a; r.v -= c; return r; }
 template <int P> __device__ __forceinline__ Dual<P> operator*(const Dual<P>& a, double c) { Dual<P> r; r.v = a.v * c; for (int j = 0; j < P; ++j) r.d[j] = a.d[j] * c; return r; }
@@ -25,7 +25,7 @@ template <int P> __device__ __forceinline__ Dual<P> operator+(double c, const Du
 template <int P> __device__ __forceinline__ Dual<P> operator-(double c, const Dual<P>& a) { Dual<P> r; r.v = c - a.v; for (int j = 0; j < P; ++j) r.d[j] = -a.d[j]; return r; }
 template <int P> __device__ __forceinline__ Dual<P> operator/(double c, const Dual<P>& a) { return dconst<P>(c) / a; }
 template <int P> __device__ __forceinline__ Dual<P> dexp(const Dual<P>& a) { Dual<P> r; r.v = mcx_exp(a.v); for (int j = 0; j < P; ++j) r.d[j] = r.v * a.d[j]; return r; }
-template <int P> __device__ __forceinline__ Dual<P> dlog(const Dual<P>& a) { Dual<P> r; r.v = mcx_log(a.v); const double ia = 1.0 / a.v; for (int j = 0; j < P; ++j) r.d[j] = a.d[j] * ia; return r; }
+template <int P> __device__ __forceinline__ Dual<P> dlog(const Dual<P>& a) { Dual<P> r; r.v = mcx_log(a.v); const double ia = mcx_rcp(a.v); for (int j = 0; j < P; ++j) r.d[j] = a.d[j] * ia; return r; }
 // sqrt: a zero tangent stays zero even where 1/(2 sqrt(x)) is infinite (x clamped to 0).  Reverse mode gets the same result
 // because torch.clamp's backward is a `where(mask, grad, 0)` that discards the inf/NaN produced by sqrt's backward.
 template <int P> __device__ __forceinline__ Dual<P> dsqrt(const Dual<P>& a) { Dual<P> r; r.v = mcx_sqrt(a.v); const double h = 0.5 / r.v; for (int j = 0; j < P; ++j) r.d[j] = a.d[j] == 0.0 ? 0.0 : a.d[j] * h; return r; }

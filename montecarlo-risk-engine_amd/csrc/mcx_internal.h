@@ -109,6 +109,7 @@ struct mcx_sim {
     mcx_step* d_steps;
     double* d_chol;
     double* d_aux;
+    std::vector<mcx_step> h_steps; // host copy of the sub-step table (per-step records derived from it: kt_tangent.hip)
     int n_state_total;
     int state_dim[MCX_MAX_SLOTS];
 };

@@ -29,9 +29,15 @@ class Shard:
             return like.device if like is not None and like.is_cuda else torch.device("cuda", torch.cuda.current_device())
         return torch.device("cpu")
 
+    @property
+    def _trivial(self) -> bool:
+        """no collective needed: no process group, or a one-rank gloo group.  A one-rank RCCL group still goes through the
+        collectives, so that a single GPU exercises exactly the code eight GPUs run"""
+        return not self.active or (self.world == 1 and self.backend != "nccl")
+
     def all_reduce_(self, t: torch.Tensor) -> torch.Tensor:
         """in-place sum over ranks of a device (nccl) or host (gloo) tensor"""
-        if not self.active or self.world == 1:
+        if self._trivial:
             return t
         dev = self._comm_device(t)
         if t.device == dev:
@@ -43,7 +49,7 @@ class Shard:
         return t
 
     def all_reduce_np(self, a: np.ndarray) -> np.ndarray:
-        if not self.active or self.world == 1:
+        if self._trivial:
             return a
         t = torch.from_numpy(np.ascontiguousarray(a)).to(self._comm_device())
         dist.all_reduce(t, group=self.group)
@@ -66,7 +72,7 @@ class Shard:
         """stack equal-shaped float64 arrays of all ranks along a new leading axis (the single small collective that
         carries the (n, shift, s1, s2) accumulator records of every metric)"""
         a = np.ascontiguousarray(a, dtype=np.float64)
-        if not self.active or self.world == 1:
+        if self._trivial:
             return a[None]
         t = torch.from_numpy(a).to(self._comm_device())
         if self.backend == "nccl":

@@ -392,11 +392,18 @@ def test_rccl_collectives_single_rank_group(hip):
         assert float(t.sum()) == 5.0
         sc, _ = cases.make_controller("irs_cva", hip, inject=False)       # a whole run with an active (one-rank) process group
         a = sc.run_simulation().results[0][0][0]
+        # Bermudan swaption with EPE + PFE: all-reduce of the LSM moments per date and of the select histograms per digit pass
+        sb, _ = cases.make_controller("bermudan_swaption", hip, inject=False)
+        ab = sb.run_simulation().results
     finally:
         dist.destroy_process_group()
     sc2, _ = cases.make_controller("irs_cva", hip, inject=False)
     b = sc2.run_simulation().results[0][0][0]
     assert a[0] == b[0]
+    sb2, _ = cases.make_controller("bermudan_swaption", hip, inject=False)
+    bb = sb2.run_simulation().results
+    for m in range(len(bb[0])):
+        np.testing.assert_allclose(np.array(ab[0][m], dtype=float), np.array(bb[0][m], dtype=float), rtol=1e-9, atol=1e-12)
 
 
 def test_simulate_time_step_api_on_the_gpu(hip):
