@@ -202,7 +202,7 @@ class _NoTangentForm(Exception):
     pass
 
 
-def _host_descriptors(sc, model=None):
+def _host_descriptors(sc, model=None, dtype=np.float64):
     """every host-computed number the kernels consume (slot parameters, initial state, per-step tables, atom coefficients) of a
     COMPILED controller, re-evaluated under `model` (default: its own) WITHOUT touching the GPU.  Only the model-dependent
     numbers are recomputed: the per-step tables of the existing sub-step schedule and the closed-form coefficients of the
@@ -210,14 +210,14 @@ def _host_descriptors(sc, model=None):
     model = sc.model if model is None else model
     sim, comp = sc.sim_plan, sc._comp
     specs = model._slots()
-    slots = np.zeros((sim.n_slots, _abi.SLOT_NPARAM))
+    slots = np.zeros((sim.n_slots, _abi.SLOT_NPARAM), dtype=dtype)
     for s, sp in enumerate(specs):
         slots[s, :len(sp.params)] = sp.params
-    aux = np.zeros_like(sim.aux)
+    aux = np.zeros(sim.aux.shape, dtype=dtype)
     for k in range(sim.n_steps):
         for s, vals in enumerate(model._step_aux(sim.scheme, float(sim.steps["t1"][k]), float(sim.steps["dt"][k]))):
             aux[k, s, :len(vals)] = vals
-    atoms = np.zeros((len(comp.atoms), 5))
+    atoms = np.zeros((len(comp.atoms), 5), dtype=dtype)
     cols = []
     for q, src in enumerate(comp.atom_src):
         if src is None:
@@ -228,7 +228,15 @@ def _host_descriptors(sc, model=None):
         atoms[q] = (co.a, co.d, co.b, co.c0, co.c1)
         cols.append(-1 if co.col is None else co.col)
     shape = (tuple(cols), tuple(sp.kind for sp in specs))
-    return dict(slots=slots, init=np.array(model._initial_state(), dtype=np.float64), aux=aux, atoms=atoms), shape
+    return dict(slots=slots, init=np.array(model._initial_state(), dtype=dtype), aux=aux, atoms=atoms), shape
+
+
+def _set_complex_step(model, j: int, h: float):
+    """evaluate the closed forms at theta_j + i h (Model._pf): j indexes `model.get_model_params()`"""
+    for m in _leaf_models(model):
+        n = len(m.model_params)
+        m._complex_step = [complex(float(p.detach()), h if q == j else 0.0) for q, p in enumerate(m.model_params)]
+        j -= n
 
 
 def _solve_dual(mom: np.ndarray, K: int, shift: float, scale: float, degenerate: bool, n_par: int):
@@ -306,19 +314,39 @@ def run_with_tangent_book(sc):
         return m
 
     dd = {k: np.zeros(v.shape + (P,)) for k, v in d0.items()}
-    four_point = os.environ.get("MCX_DESCRIPTOR_FD", "4") == "4"
-    for j in range(P):
-        h = (1e-3 if four_point else 1e-4) * max(abs(theta[j]), 1e-2)
-        ev = {}
-        for mult in ((1, -1, 2, -2) if four_point else (1, -1)):
-            ev[mult], shp = _host_descriptors(base, bumped_model(j, theta[j] + mult * h))
-            if shp != shape0:
-                raise _NoTangentForm("descriptor structure depends on the parameters")
-        for k in dd:
-            if four_point:
-                dd[k][..., j] = (8.0 * (ev[1][k] - ev[-1][k]) - (ev[2][k] - ev[-2][k])) / (12.0 * h)
-            else:
-                dd[k][..., j] = (ev[1][k] - ev[-1][k]) / (2.0 * h)
+    # Complex step: the closed forms are analytic in the parameters, so d f / d theta = Im f(theta + i h) / h with h far below
+    # rounding — ONE evaluation per parameter, no subtractive cancellation (exact to the last bits).  Models whose closed forms
+    # are not complex-safe fall back to 4-point central differences with a wide step (truncation O(h^4) ~ 1e-12, rounding
+    # eps/h ~ 1e-13 relative; a 2-point formula with h = 1e-6 left 1e-5 relative noise on d CVA / d sigma_cir).
+    mode = os.environ.get("MCX_DESCRIPTOR_FD", "complex")
+    if mode == "complex":
+        try:
+            for j in range(P):
+                m = copy.deepcopy(sc.model)
+                m.perform_smoothing = smoothing
+                h = 1e-30 * max(abs(theta[j]), 1e-2)
+                _set_complex_step(m, j, h)
+                ev, shp = _host_descriptors(base, m, dtype=np.complex128)
+                if shp != shape0:
+                    raise _NoTangentForm("descriptor structure depends on the parameters")
+                for k in dd:
+                    dd[k][..., j] = ev[k].imag / h
+        except TypeError:                     # a closed form written with real-only functions
+            mode = "4"
+    if mode != "complex":
+        four_point = mode == "4"
+        for j in range(P):
+            h = (1e-3 if four_point else 1e-4) * max(abs(theta[j]), 1e-2)
+            ev = {}
+            for mult in ((1, -1, 2, -2) if four_point else (1, -1)):
+                ev[mult], shp = _host_descriptors(base, bumped_model(j, theta[j] + mult * h))
+                if shp != shape0:
+                    raise _NoTangentForm("descriptor structure depends on the parameters")
+            for k in dd:
+                if four_point:
+                    dd[k][..., j] = (8.0 * (ev[1][k] - ev[-1][k]) - (ev[2][k] - ev[-2][k])) / (12.0 * h)
+                else:
+                    dd[k][..., j] = (ev[1][k] - ev[-1][k]) / (2.0 * h)
     t_desc = time.perf_counter() - t0
     t_pre = t_main = 0.0
     book, sim, K = base.book, base._sim, base.book_plan.n_basis

@@ -10,7 +10,7 @@ from .. import _abi
 from ..common.enums import SimulationScheme
 from ..common.packages import FLOAT, device
 from ..request_interface.request_types import AtomicRequestType as RT
-from .model import AtomCoef, Model, SlotSpec
+from .model import cexp, csqrt, AtomCoef, Model, SlotSpec
 
 
 def deterministic_rate_atom(req, rate: float, t0: float) -> AtomCoef | None:
@@ -18,13 +18,13 @@ def deterministic_rate_atom(req, rate: float, t0: float) -> AtomCoef | None:
     FORWARD_RATE is the growth factor exp(+r (t2-t1)) — reproduced as is."""
     k = req.request_type
     if k == RT.DISCOUNT_FACTOR:
-        return AtomCoef(a=math.exp(-rate * (req.time1 - t0)))
+        return AtomCoef(a=cexp(-rate * (req.time1 - t0)))
     if k == RT.FORWARD_RATE:
-        return AtomCoef(a=math.exp(rate * (req.time2 - req.time1)))
+        return AtomCoef(a=cexp(rate * (req.time2 - req.time1)))
     if k == RT.LIBOR_RATE:
-        return AtomCoef(a=(math.exp(rate * (req.time2 - req.time1)) - 1) / (req.time2 - req.time1))
+        return AtomCoef(a=(cexp(rate * (req.time2 - req.time1)) - 1) / (req.time2 - req.time1))
     if k == RT.NUMERAIRE:
-        return AtomCoef(a=math.exp(rate * (req.time1 - t0)))
+        return AtomCoef(a=cexp(rate * (req.time1 - t0)))
     return None
 
 

@@ -11,7 +11,7 @@ from ..common.enums import SimulationScheme
 from ..common.packages import FLOAT, device
 from ..helpers.cs_helper import CSHelper
 from ..request_interface.request_types import AtomicRequestType as RT
-from .model import AtomCoef, Model, SlotSpec
+from .model import cexp, csqrt, AtomCoef, Model, SlotSpec
 
 
 class CIRPPModel(Model):
@@ -56,30 +56,30 @@ class CIRPPModel(Model):
     # ---- CIR closed forms (cirpp.py:93-142) ---------------------------------------------------------------------
     def _h(self) -> float:
         kappa, sigma = self._pf(0), self._pf(2)
-        return math.sqrt(kappa * kappa + 2.0 * sigma * sigma)
+        return csqrt(kappa * kappa + 2.0 * sigma * sigma)
 
     def _A(self, t, T) -> float:
         kappa, theta, sigma, h = self._pf(0), self._pf(1), self._pf(2), self._h()
         dt = float(T) - float(t)
-        num = 2.0 * h * math.exp(0.5 * (kappa + h) * dt)
-        den = 2.0 * h + (kappa + h) * (math.exp(h * dt) - 1.0)
+        num = 2.0 * h * cexp(0.5 * (kappa + h) * dt)
+        den = 2.0 * h + (kappa + h) * (cexp(h * dt) - 1.0)
         return (num / den) ** ((2.0 * kappa * theta) / (sigma * sigma))
 
     def _B(self, t, T) -> float:
         kappa, h = self._pf(0), self._h()
         dt = float(T) - float(t)
-        e = math.exp(h * dt) - 1.0
+        e = cexp(h * dt) - 1.0
         return (2.0 * e) / (2.0 * h + (kappa + h) * e)
 
     def _D(self, t) -> float:
         kappa, theta, sigma, h = self._pf(0), self._pf(1), self._pf(2), self._h()
-        et = math.exp(h * float(t))
+        et = cexp(h * float(t))
         num = 0.5 * (kappa + h) - (h * (kappa + h) * et) / (2.0 * h + (kappa + h) * (et - 1.0))
         return (2.0 * kappa * theta / (sigma * sigma)) * num
 
     def _E(self, t) -> float:
         kappa, h = self._pf(0), self._h()
-        et = math.exp(h * float(t))
+        et = cexp(h * float(t))
         return (4.0 * h * h * et) / (2.0 * h + (kappa + h) * (et - 1.0)) ** 2
 
     def psi(self, t) -> float:
@@ -95,7 +95,7 @@ class CIRPPModel(Model):
         t, T = float(t), float(T)
         y0 = self._pf(3)
         pref = (self._market_survival_probability(T) / self._market_survival_probability(t)) \
-            * (self._A(0.0, t) / self._A(0.0, T)) * math.exp(-self._B(0.0, t) * y0 + self._B(0.0, T) * y0)
+            * (self._A(0.0, t) / self._A(0.0, T)) * cexp(-self._B(0.0, t) * y0 + self._B(0.0, T) * y0)
         return pref * self._A(t, T), self._B(t, T)
 
     def survival_probability(self, t, T, y_t):

@@ -9,6 +9,8 @@ requests it can resolve ("atoms", see include/mcx.h).
 """
 from __future__ import annotations
 
+import cmath
+import math
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -17,6 +19,16 @@ import torch
 from ..common.enums import SimulationScheme
 from ..common.packages import FLOAT, device
 from ..request_interface.request_types import AtomicRequest
+
+
+def cexp(x):
+    """exp for the closed-form coefficient code: real in, real out; complex in (complex-step differentiation of the
+    descriptors, mcx/aad.py), complex out"""
+    return cmath.exp(x) if isinstance(x, complex) else math.exp(x)
+
+
+def csqrt(x):
+    return cmath.sqrt(x) if isinstance(x, complex) else math.sqrt(x)
 
 
 @dataclass
@@ -82,6 +94,9 @@ class Model:
         """parameter i as a Python float; memoised on the tensor's identity and in-place version counter (the closed-form
         coefficient code calls this ~10^4 times per compilation)"""
         t = self.model_params[i]
+        step = self.__dict__.get("_complex_step")
+        if step is not None:                   # complex parameter values: the closed forms are evaluated at theta + i h
+            return step[i]
         cache = self.__dict__.setdefault("_pf_cache", {})
         hit = cache.get(i)
         if hit is not None and hit[0] is t and hit[1] == t._version:

@@ -10,7 +10,7 @@ from .. import _abi
 from ..common.enums import SimulationScheme
 from ..common.packages import FLOAT, device
 from ..request_interface.request_types import AtomicRequestType as RT
-from .model import AtomCoef, Model, SlotSpec
+from .model import cexp, csqrt, AtomCoef, Model, SlotSpec
 
 
 class VasicekModel(Model):
@@ -44,14 +44,14 @@ class VasicekModel(Model):
         """P(t1,t2 | r) = exp(alpha - B r)  (vasicek.py:114-128)"""
         sigma, theta, a = self._pf(1), self._pf(2), self._pf(3)
         tau = time2 - time1
-        B = (1 - math.exp(-a * tau)) / a
+        B = (1 - cexp(-a * tau)) / a
         alpha = (theta - sigma ** 2 / (2 * a ** 2)) * (B - tau) - (sigma ** 2 / (4 * a)) * B ** 2
         return alpha, B
 
     def compute_bond_price(self, time1, time2, rate):
         alpha, B = self._zcb_coeffs(float(time1), float(time2))
         rate = torch.as_tensor(rate, dtype=FLOAT, device=device)
-        return math.exp(alpha) * torch.exp(-B * rate)
+        return cexp(alpha) * torch.exp(-B * rate)
 
     def _slots(self):
         return [SlotSpec(_abi.MODEL_VASICEK, [self._pf(i) for i in range(4)], 2, 1)]
@@ -61,7 +61,7 @@ class VasicekModel(Model):
 
     def _step_aux(self, scheme, t1, dt):
         if scheme == SimulationScheme.ANALYTICAL:
-            return [[math.exp(-self._pf(3) * dt)]]                     # vasicek.py:82
+            return [[cexp(-self._pf(3) * dt)]]                     # vasicek.py:82
         return [[]]
 
     def _atom(self, req, asset_id):
