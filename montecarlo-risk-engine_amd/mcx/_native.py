@@ -248,11 +248,12 @@ class HipBackend:
         return f
 
     def fused_run(self, fused, seed: int, path_offset: int, n_paths: int, paths=None, cfs=None, expo=None,
-                  inject_z=None, inject_u=None, device_records: bool = False):
-        """records as a host structured array, or (device_records) as a device tensor [n_records][4] without synchronising"""
+                  inject_z=None, inject_u=None, device_records: bool = False, records_out=None):
+        """records as a host structured array, or (device_records) as a device tensor [n_records][4] without synchronising
+        (records_out: a caller-owned tensor of that shape to write them to)"""
         dp = lambda t: _vp(t.data_ptr() if t is not None else 0)
         if device_records:
-            rec = self.empty(fused.plan.n_records, 4)
+            rec = records_out if records_out is not None else self.empty(fused.plan.n_records, 4)
             self._check(self.lib.mcx_fused_run_device(
                 self.h, fused.ptr, C.c_uint64(seed), C.c_uint64(path_offset), C.c_int64(n_paths), dp(paths), C.c_int64(n_paths),
                 dp(cfs), dp(expo), C.c_int64(n_paths), dp(inject_z), dp(inject_u), _vp(rec.data_ptr()), self._stream()),

@@ -751,9 +751,67 @@ class SimulationController:
         self.last_state.update(paths=paths, cfs=cfs, expo=expo)
         return self._finish_fused_records(rec, cfs, expo, paths)
 
+    # ---- pipelined passes ----------------------------------------------------------------------------------------------------
+    # A pass of the one-launch plan ends in a few hundred bytes of accumulator records.  Gathering them over RCCL, copying them
+    # to the host and merging them in Python costs tens of microseconds of latency that a 1.2 ms kernel should not wait for:
+    # fused_pass_begin() enqueues the kernel on the compute stream and the gather + copy (to pinned memory) on a side stream,
+    # fused_pass_end() waits for that copy only and merges.  With two passes in flight the compute stream never idles.
+    def pipelined_passes_available(self) -> bool:
+        be, f = self.backend, self._fused
+        if f is None or self.materialize or self._fused_needs_expo or not hasattr(be, "fused_is_straight_line"):
+            return False
+        if self.main_plan not in ("auto", "fused") or not be.fused_is_straight_line(f):
+            return False
+        return self._shard.device_collectives or self._shard.world == 1
+
+    def fused_pass_begin(self):
+        import torch.distributed as dist
+        be, f, eng, sh = self.backend, self._fused, self._main_engine, self._shard
+        pipe = self.__dict__.setdefault("_pipe", dict(slot=0, busy=[False, False], side=torch.cuda.Stream(device=be.device), host={}))
+        slot = pipe["slot"]
+        if pipe["busy"][slot]:
+            raise RuntimeError("fused_pass_begin: two passes are already in flight; call fused_pass_end first")
+        pipe["slot"] = 1 - slot
+        pipe["busy"][slot] = True
+        n_rec = f.plan.n_records
+        host = pipe["host"].get(slot)
+        if host is None or tuple(host.shape) != (sh.world, n_rec, 4):
+            host = pipe["host"][slot] = torch.empty((sh.world, n_rec, 4), dtype=torch.float64).pin_memory()
+        run = lambda out: be.fused_run(f, eng.seed, eng.path_offset, eng.num_paths, inject_z=eng.inject_z, inject_u=eng.inject_u,
+                                       device_records=True, records_out=out)
+        if not sh.device_collectives:
+            # one GPU, no process group: the merge kernel writes its few hundred bytes straight into pinned host memory (the
+            # same address on the device); nothing but an event follows the kernel on the compute stream
+            run(host[0])
+            done = torch.cuda.Event()
+            done.record()
+            return (slot, host, done)
+        rec = self._buffer(f"pipe_rec{slot}", n_rec, 4)
+        run(rec)
+        launched = torch.cuda.Event()
+        launched.record()
+        with torch.cuda.stream(pipe["side"]):
+            pipe["side"].wait_event(launched)
+            g = self._buffer(f"pipe_gather{slot}", sh.world, n_rec, 4)
+            dist.all_gather_into_tensor(g, rec, group=sh.group)                    # RCCL orders itself after the side stream
+            host.copy_(g, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+        return (slot, host, done)
+
+    def fused_pass_end(self, ticket):
+        slot, host, done = ticket
+        done.synchronize()
+        g = host.numpy().copy()
+        self._pipe["busy"][slot] = False
+        self.last_state.update(paths=None, cfs=None, expo=None)
+        return self._finish_fused_records(g)
+
     def _finish_fused_records(self, rec, cfs=None, expo=None, paths=None):
         f = self._fused
-        if isinstance(rec, torch.Tensor):
+        if isinstance(rec, np.ndarray) and rec.ndim == 3:
+            g = rec                                                               # already gathered: [world][n_rec][4]
+        elif isinstance(rec, torch.Tensor):
             g = self._shard.all_gather_dev(rec).cpu().numpy()                     # [world][n_rec][4]
         else:
             g = self._shard.all_gather_np(rec.view(np.float64).reshape(-1, 4))

@@ -392,6 +392,18 @@ def test_rccl_collectives_single_rank_group(hip):
         assert float(t.sum()) == 5.0
         sc, _ = cases.make_controller("irs_cva", hip, inject=False)       # a whole run with an active (one-rank) process group
         a = sc.run_simulation().results[0][0][0]
+        # two passes in flight (gather + host copy of pass k behind the kernel of pass k+1): same records as the plain pass
+        sc.materialize = False
+        assert sc.pipelined_passes_available()
+        t1 = sc.fused_pass_begin(); t2 = sc.fused_pass_begin()
+        r1 = sc.fused_pass_end(t1); t3 = sc.fused_pass_begin(); r2 = sc.fused_pass_end(t2); r3 = sc.fused_pass_end(t3)
+        assert tuple(r1[0][0][0]) == tuple(a) and tuple(r2[0][0][0]) == tuple(a) and tuple(r3[0][0][0]) == tuple(a)
+        with pytest.raises(RuntimeError):
+            ta, tb = sc.fused_pass_begin(), sc.fused_pass_begin()
+            try:
+                sc.fused_pass_begin()
+            finally:
+                sc.fused_pass_end(ta); sc.fused_pass_end(tb)
         # Bermudan swaption with EPE + PFE: all-reduce of the LSM moments per date and of the select histograms per digit pass
         sb, _ = cases.make_controller("bermudan_swaption", hip, inject=False)
         ab = sb.run_simulation().results
@@ -400,6 +412,9 @@ def test_rccl_collectives_single_rank_group(hip):
     sc2, _ = cases.make_controller("irs_cva", hip, inject=False)
     b = sc2.run_simulation().results[0][0][0]
     assert a[0] == b[0]
+    sc2.materialize = False
+    assert sc2.pipelined_passes_available()                  # without a process group: the same pipeline, no collective
+    assert tuple(sc2.fused_pass_end(sc2.fused_pass_begin())[0][0][0]) == tuple(b)
     sb2, _ = cases.make_controller("bermudan_swaption", hip, inject=False)
     bb = sb2.run_simulation().results
     for m in range(len(bb[0])):
