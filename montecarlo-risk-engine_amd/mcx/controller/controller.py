@@ -253,7 +253,7 @@ class SimulationController:
             skip = self._can_skip_monte_carlo_for_product(p)
             comp.current_product = p_i
             cash = [] if skip else p._cash_events(comp)
-            pdates = [float(t) for t in p.product_timeline]
+            pdates = p.product_timeline.tolist()
             assert skip or len(cash) == len(pdates)
 
             def emit_cash(ce):
@@ -329,8 +329,8 @@ class SimulationController:
     def _regression_schedule(self, p_i: int, product: Product):
         """backward list of (t_reg, roll_begin, roll_end, store_prod_idx|None, store_expo_idx|None).  Memoised on the
         product's timelines: books of thousands of products share a handful of distinct schedules."""
-        pdates = tuple(float(t) for t in product.product_timeline)
-        preg = tuple(float(t) for t in product.regression_timeline)
+        pdates = tuple(product.product_timeline.tolist())
+        preg = tuple(product.regression_timeline.tolist())
         cache = self.__dict__.setdefault("_sched_cache", {})
         hit = cache.get((pdates, preg))
         if hit is not None:

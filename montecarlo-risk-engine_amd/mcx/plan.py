@@ -174,18 +174,28 @@ class BookCompiler:
     def events_array(self) -> np.ndarray:
         if not self.events:
             return np.zeros(0, dtype=_abi.EVENT_DTYPE)
-        parts, run = [], []
+        # one preallocated array filled slice by slice (np.concatenate of 10^4 structured blocks re-derives the common dtype
+        # per block: a quarter of the compile time of a 5,000-product book)
+        out = np.empty(self.n_events, dtype=_abi.EVENT_DTYPE)
+        pos, run = 0, []
+
+        def flush():
+            nonlocal pos, run
+            if run:
+                out[pos:pos + len(run)] = np.array(run, dtype=_abi.EVENT_DTYPE)
+                pos += len(run)
+                run = []
+
         for e in self.events:
             if isinstance(e, np.ndarray):
-                if run:
-                    parts.append(np.array(run, dtype=_abi.EVENT_DTYPE))
-                    run = []
-                parts.append(e)
+                flush()
+                out[pos:pos + len(e)] = e
+                pos += len(e)
             else:
                 run.append(e)
-        if run:
-            parts.append(np.array(run, dtype=_abi.EVENT_DTYPE))
-        return np.ascontiguousarray(np.concatenate(parts)) if len(parts) > 1 else np.ascontiguousarray(parts[0])
+        flush()
+        assert pos == self.n_events
+        return out
 
 
 class BookPlan:
