@@ -4,10 +4,17 @@ on the GPU and on the CPU oracle with identical Philox counters; cashflows, expo
 event family the kernel is specialised for: plain cashflows / exposures (four paths per lane), per-term numeraires, exercise
 products, basket / binary payoffs, analytic Black-Scholes exposures.  (profiles/r02_book_variants_kernel_stats.csv lists the
 kernels this module launched.)"""
+import os
+import sys
+
 import numpy as np
 import pytest
 
 import cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 from mcx.controller.controller import SimulationController
 
 pytestmark = pytest.mark.gpu
