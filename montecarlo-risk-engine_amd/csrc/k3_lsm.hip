@@ -32,6 +32,7 @@ struct K3Args {
     uint8_t* __restrict__ ex_bits;         // exercise-decision record / replay (mcx_book_set_exercise_replay)
     int64_t ex_ld;
     int32_t ex_mode, ev_base;              // ev_base: book index of events[0]
+    const double* etab;                    // the block's LDS copy of the 2^(j/128) table (set by the kernel, mcx_exp_tab)
 };
 
 __device__ __forceinline__ double k3_poly(const double* __restrict__ c, int K, double x)
@@ -65,13 +66,20 @@ __device__ __forceinline__ double k3_cash_event(const DevEvent& e, const K3Args&
     }
     const bool basket = e.kind == MCX_EV_OPTION && e.aux[0] != 0.0;       // geometric aggregate needed (basket_option.py:56-82)
     AtomCache ac = {-1, -1, 0.0};
-    for (int j = e.term_begin; j < e.term_end; ++j) {
-        const DevTerm tm = ldk_struct(&a.terms[j]);
-        const double av = dev_atom_cached(tm.atom, a.paths, D, a.ld, i, ac);
-        const double v = tm.w * av;
-        if (basket) glog = fma(tm.w, mcx_log(av + 1e-10), glog);
-        if (tm.den < 0) common += v;
-        else own += v / dev_atom(ldk_struct(&a.atoms[tm.den]), a.paths, D, a.ld, i);
+    if (e.term_end > e.term_begin) {
+        // the term records are read one iteration ahead (a Bermudan swaption's exercise value has up to 64 of them: the scalar
+        // load of term j+1 is in flight while term j's exponential is evaluated)
+        const mcx_expq_coef ec = mcx_expq_load();
+        DevTerm tm = ldk_struct(&a.terms[e.term_begin]);
+        for (int j = e.term_begin; j < e.term_end; ++j) {
+            const DevTerm nx = ldk_struct(&a.terms[j + 1 < e.term_end ? j + 1 : j]);
+            const double av = dev_atom_cached_tab(tm.atom, a.paths, D, a.ld, i, ac, a.etab, ec);
+            const double v = tm.w * av;
+            if (basket) glog = fma(tm.w, mcx_log(av + 1e-10), glog);
+            if (tm.den < 0) common += v;
+            else own += v / dev_atom(ldk_struct(&a.atoms[tm.den]), a.paths, D, a.ld, i);
+            tm = nx;
+        }
     }
     if (e.kind == MCX_EV_CASHFLOW) return common / num + own;
     imm = fmax(e.sign * (common - e.strike), 0.0);
@@ -160,9 +168,14 @@ __device__ __forceinline__ void k3_block_reduce(const double (&acc)[NM], double*
 }
 
 template <int K, int S>
-__global__ __launch_bounds__(MCX_BLOCK) void k3_step_valu(const K3Args a)
+__global__ __launch_bounds__(MCX_BLOCK) void k3_step_valu(const K3Args a_in)
 {
     constexpr int NM = (2 * K - 1) + S * K;
+    __shared__ double etab[MCX_EXP_LDS_DOUBLES];
+    mcx_exp_tab_load(etab);
+    __syncthreads();
+    K3Args a = a_in;
+    a.etab = etab;
     double acc[NM];
 #pragma unroll
     for (int q = 0; q < NM; ++q) acc[q] = 0.0;
@@ -188,10 +201,15 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 #define K3_FROW 66   // LDS row stride (doubles) of the [feature][path] image: 2*feature mod 32 spreads the 16 rows over banks
 
 template <int K, int S>
-__global__ __launch_bounds__(MCX_BLOCK) void k3_step_mfma(const K3Args a)
+__global__ __launch_bounds__(MCX_BLOCK) void k3_step_mfma(const K3Args a_in)
 {
     constexpr int NF = K + S;                  // features per path (<= 16)
     constexpr int NM = (2 * K - 1) + S * K;
+    __shared__ double etab[MCX_EXP_LDS_DOUBLES];
+    mcx_exp_tab_load(etab);
+    __syncthreads();
+    K3Args a = a_in;
+    a.etab = etab;
     __shared__ double feat[4][16 * K3_FROW];   // one image per wave
     __shared__ double gram[4][256];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -255,6 +273,10 @@ template <int K, int S>
 __global__ __launch_bounds__(MCX_BLOCK) void k3_step_batch(K3Args a, const K3Job* __restrict__ jobs, int blocks_per_job)
 {
     constexpr int NM = (2 * K - 1) + S * K;
+    __shared__ double etab[MCX_EXP_LDS_DOUBLES];
+    mcx_exp_tab_load(etab);
+    __syncthreads();
+    a.etab = etab;
     const K3Job jb = ldk_struct(&jobs[blockIdx.y]);
     a.events += jb.ev_off; a.ev_base = jb.ev_off; a.roll_begin = jb.roll_begin; a.roll_end = jb.roll_end; a.W += jb.w_off;
     a.shift = jb.shift; a.scale = jb.scale; a.num = jb.num; a.x = jb.x;
@@ -501,6 +523,7 @@ static int lsm_step_launch(mcx_handle* h, const mcx_book* b, int32_t product, in
     if ((size_t)grid * NM * sizeof(double) > h->ws_bytes) MCX_FAIL(h, -2, "%s: workspace too small", who);
     auto flat = [&](int id) { DevAtom o; const mcx_atom& q = b->h_atoms[id]; o.t_idx = q.t_idx; o.col = q.col; o.a = q.a; o.d = q.d; o.b = q.b; o.c0 = q.c0; o.c1 = q.c1; return o; };
     K3Args a;
+    a.etab = nullptr;
     a.terms = b->d_terms; a.events = b->d_events + pr.cf_begin; a.atoms = b->d_atoms; a.coeffs = b->d_coeffs; a.paths = d_paths;
     a.W = d_W; a.partials = h->d_ws; a.num = flat(num_atom); a.x = flat(x_atom); a.shift = shift; a.scale = scale;
     a.n = n_paths; a.ld = ld; a.ld_w = ld_w; a.roll_begin = roll_begin; a.roll_end = roll_end; a.n_basis = K; a.n_state = b->n_state;
@@ -610,6 +633,7 @@ extern "C" int mcx_lsm_step_batch(mcx_handle* h, const mcx_book* b, const mcx_ls
     double* d_out = (double*)mcx_scratch(h, 3, sizeof(double) * (size_t)chunk * NM);
     if (!d_jobs || !d_part || !d_out) return -100;
     K3Args a;
+    a.etab = nullptr;
     memset(&a, 0, sizeof(a));
     a.terms = b->d_terms; a.events = b->d_events; a.atoms = b->d_atoms; a.coeffs = b->d_coeffs; a.paths = d_paths;
     a.W = d_W; a.partials = d_part; a.n = n_paths; a.ld = ld; a.ld_w = ld_w; a.n_basis = K; a.n_state = b->n_state;

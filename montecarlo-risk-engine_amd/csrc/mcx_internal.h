@@ -181,6 +181,24 @@ __device__ __forceinline__ double dev_atom_cached(const DevAtom& a, const double
     return v;
 }
 
+// dev_atom_cached with the exponential from the block's LDS table (mcx_exp_tab)
+__device__ __forceinline__ double dev_atom_cached_tab(const DevAtom& a, const double* __restrict__ paths, int64_t D, int64_t ld, int64_t i,
+                                                      AtomCache& c, const double* __restrict__ etab, const mcx_expq_coef& ec)
+{
+    double x = 0.0;
+    if (a.col >= 0) {
+        if (a.t_idx != c.t_idx || a.col != c.col) {           // wave-uniform test
+            c.x = paths[((int64_t)a.t_idx * D + a.col) * ld + i];
+            c.t_idx = a.t_idx; c.col = a.col;
+        }
+        x = c.x;
+    }
+    double v = fma(a.d, x, a.a);
+    if (a.b != 0.0) v = fma(a.b, mcx_exp_tab(fma(a.c1, x, a.c0), etab, ec), v);
+    return v;
+}
+
+
 // exercise decision with optional record / replay (mcx_book_set_exercise_replay): `cell` = the (event, path) byte, `bit` = the
 // hypothetical start state of the LSM roll (0 in the main simulation)
 __device__ __forceinline__ bool dev_exercise_decision(bool decided, int s, int mode, uint8_t* __restrict__ cell, int bit)
