@@ -70,6 +70,8 @@ enum {
  *   CIRPP_DET any:        aux0 = lambda_mkt(t1), aux1 = lambda_mkt(t2)
  *   S2F       ANALYTICAL: aux0 = exp(-kappa dt) (1 when kappa ~ 0), aux1 = log F0(t2)        EULER: aux1 = log F0(t2)
  *   HESTON    QE:         aux0 = E = exp(-kappa dt), aux1..aux5 = K0..K4, aux6 = sigma^2 E (1-E)/kappa, aux7 = theta sigma^2 (1-E)^2/(2 kappa)
+ * Under EULER, aux4..aux6 of BS / VASICEK / CIRPP slots are reserved: mcx_sim_create overwrites them in its device copy with
+ * step constants derived from the slot parameters and dt (drift and diffusion factors); the caller's array is not modified.
  */
 
 #define MCX_FLAG_SMOOTHING 1  /* Model.perform_smoothing (fuzzy QE branches), model.py:83-90 */

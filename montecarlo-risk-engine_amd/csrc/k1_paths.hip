@@ -140,8 +140,24 @@ extern "C" int mcx_sim_create(mcx_handle* h, const mcx_sim_desc* d, mcx_sim** ou
     if (e == hipSuccess) e = hipMalloc(&sim->d_chol, nb_chol);
     if (e == hipSuccess) e = hipMalloc(&sim->d_aux, nb_aux);
     if (e == hipSuccess && d->n_steps > 0) e = hipMemcpy(sim->d_steps, d->steps, sizeof(mcx_step) * d->n_steps, hipMemcpyHostToDevice);
-    if (e == hipSuccess && d->n_steps > 0)
-        e = hipMemcpy(sim->d_aux, d->aux, sizeof(double) * (size_t)d->n_steps * d->n_slots * MCX_AUX, hipMemcpyHostToDevice);
+    if (e == hipSuccess && d->n_steps > 0) {
+        std::vector<double> aux(d->aux, d->aux + (size_t)d->n_steps * d->n_slots * MCX_AUX);
+        if (d->scheme == MCX_SCHEME_EULER) {
+            for (int k = 0; k < d->n_steps; ++k)
+                for (int q = 0; q < d->n_slots; ++q) {
+                    double* a = aux.data() + ((size_t)k * d->n_slots + q) * MCX_AUX;
+                    const double* p = d->slots[q].p;
+                    const double dt = d->steps[k].dt, sq = d->steps[k].sqrt_dt;
+                    switch (d->slots[q].kind) {
+                    case MCX_MODEL_BS: a[MCX_AUX_C0] = p[2] * dt; a[MCX_AUX_C2] = p[1] * sq; break;
+                    case MCX_MODEL_VASICEK: a[MCX_AUX_C0] = p[3] * p[2] * dt; a[MCX_AUX_C1] = -(p[3] * dt); a[MCX_AUX_C2] = p[1] * sq; break;
+                    case MCX_MODEL_CIRPP: a[MCX_AUX_C0] = p[0] * p[1] * dt; a[MCX_AUX_C1] = -(p[0] * dt); a[MCX_AUX_C2] = p[2] * sq; break;
+                    default: break;
+                    }
+                }
+        }
+        e = hipMemcpy(sim->d_aux, aux.data(), sizeof(double) * aux.size(), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess && d->n_chol > 0)
         e = hipMemcpy(sim->d_chol, d->chol, sizeof(double) * (size_t)d->n_chol * d->n_z * d->n_z, hipMemcpyHostToDevice);
     if (e != hipSuccess) {                      // nothing of a failed create survives

@@ -20,6 +20,7 @@
 //     a "region zero" (mcx_math.h), i.e. as scalar loads at the point of use.  Left alone, the backend loads all ~100
 //     argument dwords in the prologue, keeps them live through every loop and spills them to VGPR lanes; each reload is a
 //     v_readlane — a VALU instruction, the pipe this kernel is bound by (the round-1 kernel carried 82 such spills).
+#define MCX_BM_BITS 10          // 1024-entry Box-Muller tables (32 KiB of LDS: four blocks per CU fit), see mcx_math.h
 #include "kf_common.h"
 
 namespace {
@@ -322,10 +323,11 @@ __global__ __launch_bounds__(MCX_BLOCK, MCX_LEAN_WAVES) void kf_lean(const Fused
                 const auto& k = kargs_region(zr).k1;
                 const uint64_t seed = k.seed;
                 const mcx_bm_coef bc = mcx_bm_coef_load(zr);
+                const mcx_bm_vconst vc = mcx_bm_vconst_make(bc);  // constants kept in registers across the run of sub-steps
 #pragma unroll 1
                 while (st < 0 && step < n_steps) {
 #pragma unroll
-                    for (int q = 0; q < PPL; ++q) sim_substep<NSLOT, NZ, INJECT, SIG>(k, step, path[q], i[q], reg[q], tab, seed, bc);
+                    for (int q = 0; q < PPL; ++q) sim_substep<NSLOT, NZ, INJECT, SIG>(k, step, path[q], i[q], reg[q], tab, seed, bc, &vc);
                     st = ldk(&k.steps[step].store_idx);
                     ++step;
                 }

@@ -52,13 +52,13 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     o0 = c0; o1 = c1; o2 = c2; o3 = c3;
 }
 
-__device__ __forceinline__ double u53(uint32_t lo, uint32_t hi)
+__device__ __forceinline__ double u53(uint32_t lo, uint32_t hi, const mcx_bm_vconst* vc = nullptr)
 {
     // ((x >> 11) + 0.5) * 2^-53 with x = hi:lo, evaluated as hi*2^-32 + ((lo >> 11)*2^-53 + 2^-54): the inner sum is exact and the
-    // outer fma rounds once, exactly like the oracle's (double)(x >> 11) + 0.5
+    // outer fma rounds once, exactly like the oracle's (double)(x >> 11) + 0.5.  vc: loop-resident constants (mcx_math.h)
+    if (vc) return fma((double)hi, vc->s32, fma((double)(lo >> 11), vc->s53, vc->c54));
     return fma((double)hi, 0x1.0p-32, fma((double)(lo >> 11), 0x1.0p-53, 0x1.0p-54));
 }
-
 
 // ---- barrier options (barrier_option.py:60-223): MCX_EV_OPTION modes 4 (discrete monitoring) and 5 (+ Brownian bridge) ------
 // RNG state of the bridge draws, one per book (mcx_book_set_bridge_rng): production draws are Philox4x32-10 with key = seed and
@@ -126,19 +126,22 @@ __device__ __forceinline__ double dev_barrier_event(const DevEvent& e, const Dev
 // TAB: `tab` is the block's LDS copy of the Box-Muller tables (mcx_bm_load); otherwise polynomial log / sincos
 template <bool TAB = false>
 __device__ __forceinline__ void draw_pair(uint64_t seed, uint64_t path, uint32_t step, uint32_t draw, double& ua, double& z0, double& z1,
-                                          const double* __restrict__ tab, const mcx_bm_coef& bc)
+                                          const double* __restrict__ tab, const mcx_bm_coef& bc, const mcx_bm_vconst* vc = nullptr)
 {
     uint32_t w0, w1, w2, w3;
     philox4x32_10((uint32_t)path, (uint32_t)(path >> 32), step, draw, (uint32_t)seed, (uint32_t)(seed >> 32), w0, w1, w2, w3);
-    ua = u53(w0, w1);
-    const double ub = u53(w2, w3);
+    ua = u53(w0, w1, vc);
     double s, c, r;
     if (TAB) {
-        r = mcx_sqrt_g(mcx_m2log_tab(ua, tab, bc));
-        mcx_sincos2pi_tab(ub, tab, s, c, bc);
+        r = mcx_sqrt_gp(mcx_m2log_tab(ua, tab, bc, vc));      // u < 1: the squared radius is > 0
+        // second uniform u = ((x >> 11) + 0.5) 2^-53, x = w3:w2: its top MCX_BM_BITS bits are the table cell, the rest is u - j/N
+        // (the same conversion on the masked word, exact)
+        const int j = (int)(w3 >> (32 - MCX_BM_BITS));
+        const double ur = u53(w2, w3 & ((1u << (32 - MCX_BM_BITS)) - 1u), vc);
+        mcx_sincos2pi_tab(ur, j, tab, s, c, bc, vc);
     } else {
         r = mcx_sqrt(-2.0 * mcx_log(ua));
-        mcx_sincos2pi(ub, s, c);
+        mcx_sincos2pi(u53(w2, w3), s, c);
     }
     z0 = r * c;
     z1 = r * s;
@@ -175,14 +178,24 @@ __device__ __forceinline__ void step_slot(const SL& sl, int scheme_rt, int flags
         if (scheme == MCX_SCHEME_ANALYTICAL) {
             s0 = s0 * mcx_exp(ldk(aux + 0) + (zc0 - ldk(aux + 1)));                       // black_scholes.py:61-67
         } else {
-            s0 = s0 + (p[2] * s0 * dt + p[1] * s0 * sq * zc0);           // black_scholes.py:79-85
+            // black_scholes.py:79-85, S + (r S dt + sigma S sqrt(dt) z) = S + S (r dt + sigma sqrt(dt) z); the step constants
+            // r dt, sigma sqrt(dt) come from the derived entries of the step table (mcx_sim_create)
+            const mcx_aux_drv dc = ldk_struct((const mcx_aux_drv*)(aux + MCX_AUX_C0));
+            s0 = fma(s0, fma(dc.c2, zc0, dc.c0), s0);
         }
         break;
     case MCX_MODEL_VASICEK: {
         const double r = s0;
         s1 = s1 + r * dt;                                                 // left-endpoint integral, vasicek.py:80/107
         if (scheme == MCX_SCHEME_ANALYTICAL) s0 = (p[2] + (r - p[2]) * ldk(aux + 0)) + zc0;
-        else s0 = r + p[3] * (p[2] - r) * dt + p[1] * sq * zc0;
+        else {
+            // r - (a dt) r + sigma sqrt(dt) z + a theta dt as three accumulations INTO the state register (one scalar operand each):
+            // the state array is a register tuple indexed by the date programs, a value computed elsewhere would be copied into it
+            const mcx_aux_drv dc = ldk_struct((const mcx_aux_drv*)(aux + MCX_AUX_C0));
+            s0 = fma(dc.c1, r, s0);
+            s0 = fma(dc.c2, zc0, s0);
+            s0 = s0 + dc.c0;
+        }
         break;
     }
     case MCX_MODEL_HW: {
@@ -195,9 +208,13 @@ __device__ __forceinline__ void step_slot(const SL& sl, int scheme_rt, int flags
     case MCX_MODEL_CIRPP: {                                               // cirpp.py:188-198
         const double y = s0;
         const double sy = mcx_sqrt_g(y);                  // = sqrt(clamp(y, 0)) of cirpp.py:194: mcx_sqrt_g returns 0 for y <= 0
-        const double yn = y + p[0] * (p[1] - y) * dt + p[2] * sy * sq * zc0;
-        s1 = s1 + (y + ldk(aux + 0)) * dt;
-        s0 = fmax(yn, 1e-12);
+        // y - (kappa dt) y + (sigma sqrt(dt)) sqrt(y) z + kappa theta dt, accumulated into the state register (see VASICEK)
+        const mcx_aux_drv dc = ldk_struct((const mcx_aux_drv*)(aux + MCX_AUX_C0));
+        s1 = fma(y + ldk(aux + 0), dt, s1);
+        s0 = fma(dc.c1, y, s0);
+        s0 = fma(dc.c2 * sy, zc0, s0);
+        s0 = s0 + dc.c0;
+        s0 = fmax(s0, 1e-12);
         break;
     }
     case MCX_MODEL_CIRPP_DET:                                             // cirpp.py:155-172
@@ -311,7 +328,7 @@ __device__ __forceinline__ void step_slots(const KA& k, const mcx_step& sp, cons
 // seed / bc: the Philox key and the Box-Muller coefficients (SGPRs) of the calling code region (mcx_math.h "region zero")
 template <int NSLOT, int NZ, bool INJECT, int SIG, class KA>
 __device__ __forceinline__ void sim_substep(const KA& k, int step, uint64_t path, int64_t i, double (&reg)[2 * NSLOT],
-                                            const double* __restrict__ tab, uint64_t seed, const mcx_bm_coef& bc)
+                                            const double* __restrict__ tab, uint64_t seed, const mcx_bm_coef& bc, const mcx_bm_vconst* vc = nullptr)
 {
     const mcx_step sp = ldk_struct(&k.steps[step]);    // wave-uniform -> scalar loads
     double z[NZ], zc[NZ], u = 0.0;
@@ -324,7 +341,7 @@ __device__ __forceinline__ void sim_substep(const KA& k, int step, uint64_t path
 #pragma unroll
         for (int q = 0; q < (NZ + 1) / 2; ++q) {
             double z0, z1;
-            draw_pair<true>(seed, path, (uint32_t)step, (uint32_t)q, ua, z0, z1, tab, bc);
+            draw_pair<true>(seed, path, (uint32_t)step, (uint32_t)q, ua, z0, z1, tab, bc, vc);
             z[2 * q] = z0;
             if (2 * q + 1 < NZ) z[2 * q + 1] = z1;
         }
@@ -338,9 +355,9 @@ __device__ __forceinline__ void sim_substep(const KA& k, int step, uint64_t path
     constexpr bool UNIT_L00 = sig_scheme(SIG) == MCX_SCHEME_EULER || sig_scheme(SIG) == MCX_SCHEME_QE;
 #pragma unroll
     for (int r = 0; r < NZ; ++r) {
-        double acc = 0.0;
+        double acc = (UNIT_L00 && r == 0) ? z[0] : ldk(L + r * NZ) * z[0];
 #pragma unroll
-        for (int c = 0; c <= r; ++c) acc += (UNIT_L00 && r == 0) ? z[c] : ldk(L + r * NZ + c) * z[c];
+        for (int c = 1; c <= r; ++c) acc = fma(ldk(L + r * NZ + c), z[c], acc);
         zc[r] = acc;
     }
     const double* __restrict__ ax = k.aux + (int64_t)step * NSLOT * MCX_AUX;

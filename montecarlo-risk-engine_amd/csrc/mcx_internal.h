@@ -104,6 +104,15 @@ struct mcx_book {
     bool expo_needs_memset;
 };
 
+// derived per-step constants of the Euler maps, written by mcx_sim_create into otherwise unused entries of the DEVICE copy of
+// the step table (aux [step][slot][MCX_AUX]): the step is then a few fused multiply-adds per state instead of a chain of
+// wave-uniform products re-evaluated by every lane.  Black-Scholes: C0 = r dt, C2 = sigma sqrt(dt); Vasicek: C0 = a theta dt,
+// C1 = -a dt, C2 = sigma sqrt(dt); CIR++: C0 = kappa theta dt, C1 = -kappa dt, C2 = sigma sqrt(dt).
+#define MCX_AUX_C0 4
+#define MCX_AUX_C1 5
+#define MCX_AUX_C2 6
+struct mcx_aux_drv { double c0, c1, c2; };      // aux[MCX_AUX_C0 .. MCX_AUX_C2] as one scalar load
+
 struct mcx_sim {
     mcx_sim_desc desc;             // host copy (pointer members unused after create)
     mcx_step* d_steps;

@@ -142,14 +142,43 @@ __device__ __forceinline__ double mcx_sqrt_g(double a)
     return a > 0.0 ? g : 0.0;
 }
 
+// the same for a > 0 (the squared Box-Muller radius -2 log u, u < 1): no zero test
+__device__ __forceinline__ double mcx_sqrt_gp(double a)
+{
+    const double y = __builtin_amdgcn_rsq(a);
+    const double g = a * y;
+    const double h = 0.5 * y;
+    return fma(g, fma(-h, g, 0.5), g);
+}
+
 // ---- table-driven log / sincos for the Box-Muller transform ----------------------------------------------------------
 // The path kernel is bound by f64 VALU issue (4 clk per wave64 instruction), and ~half of a sub-step was the polynomial
 // log + sincos above (35 + 35 instructions).  A 128-entry table per function (2 x 2 KiB in LDS, one ds_read_b128 per lane —
 // the LDS pipe is otherwise idle in these kernels) shrinks the argument range by 2^7, so a degree-7 log1p and degree-6/7
 // sin/cos corrections are enough: ~16 + ~19 VALU instructions.  Absolute accuracy ~1e-16 (a few ulp of the RESULT away from
 // the table nodes); log(u) keeps full relative accuracy as u -> 1 because the last node is exactly c = 1.
+// MCX_BM_BITS (per translation unit): log2 of the table size.  7 (4 KiB of LDS per block) everywhere but in the one-launch
+// kernel (kf_lean.hip), which runs four blocks per CU and spends 10 (32 KiB) to drop two terms of the log1p polynomial and
+// one of each trigonometric correction: |t| <= 2^-11, |d| <= pi/1024.
 #include "mcx_tables.h"
-#define MCX_BM_LDS_DOUBLES 512
+#ifndef MCX_BM_BITS
+#define MCX_BM_BITS 7
+#endif
+#define MCX_BM_N (1 << MCX_BM_BITS)
+#define MCX_BM_LDS_DOUBLES (4 * MCX_BM_N)
+#if MCX_BM_BITS == 7
+#define MCX_BM_LOG_SRC MCX_LOG_TAB
+#define MCX_BM_TRIG_SRC MCX_TRIG_TAB
+#define MCX_BM_LOG_TERMS 6
+#define MCX_BM_TRIG_TERMS 3
+#elif MCX_BM_BITS == 10
+#define MCX_BM_LOG_SRC MCX_LOG_TAB_L
+#define MCX_BM_TRIG_SRC MCX_TRIG_TAB_L
+#define MCX_BM_LOG_TERMS 4
+#define MCX_BM_TRIG_TERMS 2
+#else
+#error "MCX_BM_BITS must be 7 or 10"
+#endif
 
 // [0..5] -2 log1p(t) = s + s^2 (c0 + c1 s + ...), s = -2 t: the coefficients of log1p scaled by exact powers of two
 // (c_k' = -c_k (-1/2)^k / 2), so the result is bit for bit -2 x (t + t^2 (-1/2 + t/3 - ...));
@@ -162,12 +191,37 @@ __device__ __forceinline__ mcx_bm_coef mcx_bm_coef_load(int z = 0)      // 24 SG
     return ldk_struct((const mcx_bm_coef*)(MCX_BM_C + z));
 }
 
+// Loop-resident copies of the constants that would otherwise be rebuilt inside a hot loop.  A VOP3 instruction reads at most one
+// scalar operand, so fma(c_a, x, c_b) with both coefficients in SGPRs costs a v_mov of one of them per use, and v_fmac with a
+// literal multiplier needs its constant addend copied into the destination first.  A kernel that can spare ten VGPRs builds this
+// once outside its sub-step loop: the additive constants as VGPR values, the multipliers of the uniform conversion as SGPR
+// values the optimiser cannot fold back into literals.
+struct mcx_bm_vconst {
+    double c54;            // 2^-54 (VGPR)
+    double s53, s32;       // 2^-53, 2^-32 (SGPR)
+    double log_head;       // C.c[MCX_BM_LOG_TERMS - 1] (VGPR)
+    double sin_head, cos_head;   // leading coefficients of the sin / cos corrections (VGPR)
+    double trig_off;       // -pi / N (VGPR)
+};
+__device__ __forceinline__ double mcx_opaque_v(double x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ double mcx_opaque_s(double x) { asm volatile("" : "+s"(x)); return x; }
+__device__ __forceinline__ mcx_bm_vconst mcx_bm_vconst_make(const mcx_bm_coef& C)
+{
+    mcx_bm_vconst v;
+    v.c54 = mcx_opaque_v(0x1.0p-54); v.s53 = mcx_opaque_s(0x1.0p-53); v.s32 = mcx_opaque_s(0x1.0p-32);
+    v.log_head = mcx_opaque_v(C.c[MCX_BM_LOG_TERMS - 1]);
+    v.sin_head = mcx_opaque_v(C.c[5 + MCX_BM_TRIG_TERMS]);
+    v.cos_head = mcx_opaque_v(C.c[8 + MCX_BM_TRIG_TERMS]);
+    v.trig_off = mcx_opaque_v(-3.14159265358979323846 / (double)MCX_BM_N);
+    return v;
+}
+
 // cooperative copy of both tables into the block's LDS area (MCX_BM_LDS_DOUBLES doubles); includes the barrier
 __device__ __forceinline__ void mcx_bm_load(double* __restrict__ tab)
 {
-    for (int q = threadIdx.x; q < 256; q += blockDim.x) {
-        tab[q] = -2.0 * MCX_LOG_TAB[q];            // (-2 / c, -2 log c): the radius needs -2 log u (exact scaling)
-        tab[256 + q] = MCX_TRIG_TAB[q];
+    for (int q = threadIdx.x; q < 2 * MCX_BM_N; q += blockDim.x) {
+        tab[q] = -2.0 * MCX_BM_LOG_SRC[q];         // (-2 / c, -2 log c): the radius needs -2 log u (exact scaling)
+        tab[2 * MCX_BM_N + q] = MCX_BM_TRIG_SRC[q];
     }
     __syncthreads();
 }
@@ -176,31 +230,37 @@ typedef double mcx_d2 __attribute__((ext_vector_type(2)));
 
 // -2 log(x), x a normal double in (0, 1]: the squared Box-Muller radius.  Every constant of log(x) = k ln2 + log c + log1p(m/c - 1)
 // carries the factor -2 (table, ln2 split, polynomial: all exact power-of-two scalings), so the product -2 * log costs nothing
-__device__ __forceinline__ double mcx_m2log_tab(double x, const double* __restrict__ tab, const mcx_bm_coef& C)
+__device__ __forceinline__ double mcx_m2log_tab(double x, const double* __restrict__ tab, const mcx_bm_coef& C, const mcx_bm_vconst* vc = nullptr)
 {
     const double m = __builtin_amdgcn_frexp_mant(x);                  // [0.5, 1)
     const int e = __builtin_amdgcn_frexp_exp(x);
-    const int j = (__double2hiint(m) >> 13) & 127;                     // top 7 mantissa bits
+    const int j = (__double2hiint(m) >> (20 - MCX_BM_BITS)) & (MCX_BM_N - 1);      // top mantissa bits
     const mcx_d2 tc = ((const mcx_d2*)tab)[j];                        // (-2/c, -2 log c)
-    const double s = fma(m, tc.x, 2.0);                                // -2 t, |t| <= 2^-8
-    double q = C.c[5];
+    const double s = fma(m, tc.x, 2.0);                                // -2 t, |t| <= 2^-(BITS+1)
+    double q = vc ? vc->log_head : C.c[MCX_BM_LOG_TERMS - 1];
 #pragma unroll
-    for (int k = 4; k >= 0; --k) q = fma(q, s, C.c[k]);
+    for (int k = MCX_BM_LOG_TERMS - 2; k >= 0; --k) q = fma(q, s, C.c[k]);
     const double p = fma(s * s, q, s);                                 // -2 log1p(t)
     const double dk = (double)e;
     return fma(dk, -2.0 * 6.93147180369123816490e-01, tc.y) + fma(dk, -2.0 * 1.90821492927058770002e-10, p);
 }
 
-// (sin, cos)(2 pi u), u in [0, 1]
-__device__ __forceinline__ void mcx_sincos2pi_tab(double u, const double* __restrict__ tab, double& s, double& c, const mcx_bm_coef& C)
+// (sin, cos)(2 pi u) from the cell index j = floor(u N) and the remainder ur = u - j / N in (0, 1/N) — both read off the integer
+// image of the 53-bit uniform by the caller (draw_pair: a shift and a mask instead of scaling, rounding and converting u).
+// The table nodes sit at the cell centres, angle 2 pi (j + 1/2) / N: |d| <= pi / N.
+__device__ __forceinline__ void mcx_sincos2pi_tab(double ur, int j, const double* __restrict__ tab, double& s, double& c, const mcx_bm_coef& C,
+                                                  const mcx_bm_vconst* vc = nullptr)
 {
-    const double n = rint(u * 128.0);
-    const double d = fma(n, -0.0078125, u) * 6.28318530717958647692;   // |d| <= pi/128
-    const int j = (int)n & 127;
-    const mcx_d2 sc = ((const mcx_d2*)(tab + 256))[j];
+    const double d = fma(ur, 6.28318530717958647692, vc ? vc->trig_off : -3.14159265358979323846 / (double)MCX_BM_N);
+    const mcx_d2 sc = ((const mcx_d2*)(tab + 2 * MCX_BM_N))[j];
     const double d2 = d * d;
-    const double qs = fma(fma(C.c[8], d2, C.c[7]), d2, C.c[6]);
-    const double qc = fma(fma(C.c[11], d2, C.c[10]), d2, C.c[9]);
+#if MCX_BM_TRIG_TERMS == 3
+    const double qs = fma(fma(vc ? vc->sin_head : C.c[8], d2, C.c[7]), d2, C.c[6]);
+    const double qc = fma(fma(vc ? vc->cos_head : C.c[11], d2, C.c[10]), d2, C.c[9]);
+#else
+    const double qs = fma(vc ? vc->sin_head : C.c[7], d2, C.c[6]);
+    const double qc = fma(vc ? vc->cos_head : C.c[10], d2, C.c[9]);
+#endif
     const double ps = fma(d * d2, qs, d);                              // sin d
     const double pc = fma(d2, qc, 1.0);                                // cos d
     s = fma(sc.x, pc, sc.y * ps);
