@@ -241,8 +241,9 @@ __device__ __forceinline__ double mcx_m2log_tab(double x, const double* __restri
 #pragma unroll
     for (int k = MCX_BM_LOG_TERMS - 2; k >= 0; --k) q = fma(q, s, C.c[k]);
     const double p = fma(s * s, q, s);                                 // -2 log1p(t)
-    const double dk = (double)e;
-    return fma(dk, -2.0 * 6.93147180369123816490e-01, tc.y) + fma(dk, -2.0 * 1.90821492927058770002e-10, p);
+    // -2 (e ln2 + log c) + p.  One constant for ln2: the rounding error of e * ln2 is <= 2^-54 of the RESULT (>= 2 |e| ln2 / 2), the
+    // accuracy the squared radius needs (a hi / lo split would only matter for log itself near x = 1, where e = 0 anyway)
+    return fma((double)e, -2.0 * 6.93147180559945309417e-01, tc.y) + p;
 }
 
 // (sin, cos)(2 pi u) from the cell index j = floor(u N) and the remainder ur = u - j / N in (0, 1/N) — both read off the integer
