@@ -46,9 +46,12 @@ __global__ __launch_bounds__(MCX_BLOCK) void k1_paths(const K1Args a)
     for (int t = 0; t < a.n_initial_store; ++t)
 #pragma unroll
         for (int q = 0; q < PPL; ++q) if (live[q]) sim_store_state<NSLOT, SIG>(a, t, idx[q], reg[q]);
+    const mcx_bm_coef bc = mcx_bm_coef_load();
+    const mcx_bm_vconst vc = mcx_bm_vconst_make(bc);          // Box-Muller constants kept in registers across the step loop
     for (int k = 0; k < a.n_steps; ++k) {
 #pragma unroll
-        for (int q = 0; q < PPL; ++q) sim_substep<NSLOT, NZ, INJECT, SIG>(a, k, a.path_offset + (uint64_t)idx[q], idx[q], reg[q], tab);
+        for (int q = 0; q < PPL; ++q)
+            sim_substep<NSLOT, NZ, INJECT, SIG>(a, k, a.path_offset + (uint64_t)idx[q], idx[q], reg[q], tab, a.seed, bc, &vc);
         const int st = ldk(&a.steps[k].store_idx);
         if (st >= 0)
 #pragma unroll
