@@ -20,7 +20,9 @@
 //     a "region zero" (mcx_math.h), i.e. as scalar loads at the point of use.  Left alone, the backend loads all ~100
 //     argument dwords in the prologue, keeps them live through every loop and spills them to VGPR lanes; each reload is a
 //     v_readlane — a VALU instruction, the pipe this kernel is bound by (the round-1 kernel carried 82 such spills).
-#define MCX_BM_BITS 10          // 1024-entry Box-Muller tables (32 KiB of LDS: four blocks per CU fit), see mcx_math.h
+#include <map>
+#include <utility>
+
 #include "kf_common.h"
 
 namespace {
@@ -272,12 +274,15 @@ __global__ __launch_bounds__(MCX_BLOCK, MCX_LEAN_WAVES) void kf_lean(const Fused
     const int n_rec = a0.n_rec;
     const int64_t n = a0.k1.n;
     for (int q = threadIdx.x; q < 9 * n_rec; q += MCX_BLOCK) lds[q] = 0.0;
-    constexpr int BM = (INJECT || !SIMULATE) ? 0 : MCX_BM_LDS_DOUBLES;
+    // 1024-entry Box-Muller tables (32 KiB of LDS) where the sub-steps dominate and four blocks per CU still fit: the two-factor
+    // rates / credit signature; 128 entries elsewhere (books with hundreds of per-date records need the LDS for those)
+    constexpr int BMB = SIG == SIG_VAS_CIR_E ? 10 : 7;
+    constexpr int BM = (INJECT || !SIMULATE) ? 0 : MCX_BM_LDS_DOUBLES_B(BMB);
     __shared__ double tab_lds[BM + MCX_EXP_LDS_DOUBLES];            // Box-Muller lookup tables | exp table
     const double* tab = nullptr;
     const double* etab = tab_lds + BM;
     mcx_exp_tab_load(tab_lds + BM);
-    if (BM) { mcx_bm_load(tab_lds); tab = tab_lds; }
+    if (BM) { mcx_bm_load<BMB>(tab_lds); tab = tab_lds; }
     __syncthreads();
     const int64_t tiles = (n + TILE - 1) / TILE;
     double n_block = 0.0;
@@ -323,11 +328,11 @@ __global__ __launch_bounds__(MCX_BLOCK, MCX_LEAN_WAVES) void kf_lean(const Fused
                 const auto& k = kargs_region(zr).k1;
                 const uint64_t seed = k.seed;
                 const mcx_bm_coef bc = mcx_bm_coef_load(zr);
-                const mcx_bm_vconst vc = mcx_bm_vconst_make(bc);  // constants kept in registers across the run of sub-steps
+                const mcx_bm_vconst vc = mcx_bm_vconst_make<BMB>(bc);  // constants kept in registers across the run of sub-steps
 #pragma unroll 1
                 while (st < 0 && step < n_steps) {
 #pragma unroll
-                    for (int q = 0; q < PPL; ++q) sim_substep<NSLOT, NZ, INJECT, SIG>(k, step, path[q], i[q], reg[q], tab, seed, bc, &vc);
+                    for (int q = 0; q < PPL; ++q) sim_substep<NSLOT, NZ, INJECT, SIG, BMB>(k, step, path[q], i[q], reg[q], tab, seed, bc, &vc);
                     st = ldk(&k.steps[step].store_idx);
                     ++step;
                 }
@@ -398,16 +403,40 @@ void launch_lean(const FusedArgs& a, int n_cu, bool inject, bool simulate, hipSt
 #endif
     constexpr int PPL = (SIG == SIG_GENERIC && NSLOT >= 2) ? 1 : (SIG == SIG_HESTON_QE ? MCX_LEAN_PPL_HESTON : MCX_LEAN_PPL);
     const int64_t tiles = (a.k1.n + MCX_BLOCK * PPL - 1) / (MCX_BLOCK * PPL);
-    const int64_t resident = (int64_t)MCX_LEAN_WAVES * n_cu;    // __launch_bounds__(256, 4): 4 blocks per CU, all co-resident
-    int grid = (int)tiles;
-    if (tiles > resident) {                                     // equal number of tiles per block whenever the count divides
-        const int64_t per = (tiles + resident - 1) / resident;
-        grid = (int)((tiles + per - 1) / per);
-    }
     const size_t lds = sizeof(double) * (size_t)((9 * a.n_rec + 1) & ~1);
-    if (!simulate) hipLaunchKernelGGL((kf_lean<NSLOT, NZ, false, SIG, PPL, false>), dim3(grid), dim3(MCX_BLOCK), lds, s, a);
-    else if (inject) hipLaunchKernelGGL((kf_lean<NSLOT, NZ, true, SIG, PPL, true>), dim3(grid), dim3(MCX_BLOCK), lds, s, a);
-    else hipLaunchKernelGGL((kf_lean<NSLOT, NZ, false, SIG, PPL, true>), dim3(grid), dim3(MCX_BLOCK), lds, s, a);
+    // blocks that are really co-resident: __launch_bounds__(256, 4) guarantees the registers of 4 blocks per CU, but a book with
+    // hundreds of records (one per metric date) adds dynamic LDS to the 34 KiB of tables and may leave room for 3 only; a grid
+    // sized for 4 would then run its last quarter as a tail at a third of the occupancy
+    auto residency = [&](auto kernel) {
+        thread_local std::map<std::pair<const void*, size_t>, int> cache;      // (the query costs microseconds: once per kernel and size)
+        const auto key = std::make_pair((const void*)kernel, lds);
+        auto it = cache.find(key);
+        if (it == cache.end()) {
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, MCX_BLOCK, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+            it = cache.emplace(key, per_cu < MCX_LEAN_WAVES ? per_cu : MCX_LEAN_WAVES).first;
+        }
+        return (int64_t)it->second * n_cu;
+    };
+    auto sized = [&](int64_t resident) {
+        if (tiles <= resident) return (int)tiles;
+        const int64_t per = (tiles + resident - 1) / resident;  // equal number of tiles per block whenever the count divides
+        return (int)((tiles + per - 1) / per);
+    };
+    int grid;
+    if (!simulate) {
+        auto kern = kf_lean<NSLOT, NZ, false, SIG, PPL, false>;
+        grid = sized(residency(kern));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(MCX_BLOCK), lds, s, a);
+    } else if (inject) {
+        auto kern = kf_lean<NSLOT, NZ, true, SIG, PPL, true>;
+        grid = sized(residency(kern));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(MCX_BLOCK), lds, s, a);
+    } else {
+        auto kern = kf_lean<NSLOT, NZ, false, SIG, PPL, true>;
+        grid = sized(residency(kern));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(MCX_BLOCK), lds, s, a);
+    }
     *grid_out = grid;
 }
 

@@ -124,7 +124,7 @@ __device__ __forceinline__ double dev_barrier_event(const DevEvent& e, const Dev
 
 // one draw = two uniforms in (0,1) and their Box-Muller pair (include/mcx.h "RNG contract")
 // TAB: `tab` is the block's LDS copy of the Box-Muller tables (mcx_bm_load); otherwise polynomial log / sincos
-template <bool TAB = false>
+template <bool TAB = false, int BMB = 7>
 __device__ __forceinline__ void draw_pair(uint64_t seed, uint64_t path, uint32_t step, uint32_t draw, double& ua, double& z0, double& z1,
                                           const double* __restrict__ tab, const mcx_bm_coef& bc, const mcx_bm_vconst* vc = nullptr)
 {
@@ -133,12 +133,12 @@ __device__ __forceinline__ void draw_pair(uint64_t seed, uint64_t path, uint32_t
     ua = u53(w0, w1, vc);
     double s, c, r;
     if (TAB) {
-        r = mcx_sqrt_gp(mcx_m2log_tab(ua, tab, bc, vc));      // u < 1: the squared radius is > 0
-        // second uniform u = ((x >> 11) + 0.5) 2^-53, x = w3:w2: its top MCX_BM_BITS bits are the table cell, the rest is u - j/N
+        r = mcx_sqrt_gp(mcx_m2log_tab<BMB>(ua, tab, bc, vc));      // u < 1: the squared radius is > 0
+        // second uniform u = ((x >> 11) + 0.5) 2^-53, x = w3:w2: its top BMB bits are the table cell, the rest is u - j/N
         // (the same conversion on the masked word, exact)
-        const int j = (int)(w3 >> (32 - MCX_BM_BITS));
-        const double ur = u53(w2, w3 & ((1u << (32 - MCX_BM_BITS)) - 1u), vc);
-        mcx_sincos2pi_tab(ur, j, tab, s, c, bc, vc);
+        const int j = (int)(w3 >> (32 - BMB));
+        const double ur = u53(w2, w3 & ((1u << (32 - BMB)) - 1u), vc);
+        mcx_sincos2pi_tab<BMB>(ur, j, tab, s, c, bc, vc);
     } else {
         r = mcx_sqrt(-2.0 * mcx_log(ua));
         mcx_sincos2pi(u53(w2, w3), s, c);
@@ -326,7 +326,7 @@ __device__ __forceinline__ void step_slots(const KA& k, const mcx_step& sp, cons
 
 // one sub-step of the whole model for a lane: draws, Cholesky, per-slot maps.  reg[2s], reg[2s+1] = state of slot s.
 // seed / bc: the Philox key and the Box-Muller coefficients (SGPRs) of the calling code region (mcx_math.h "region zero")
-template <int NSLOT, int NZ, bool INJECT, int SIG, class KA>
+template <int NSLOT, int NZ, bool INJECT, int SIG, int BMB = 7, class KA>
 __device__ __forceinline__ void sim_substep(const KA& k, int step, uint64_t path, int64_t i, double (&reg)[2 * NSLOT],
                                             const double* __restrict__ tab, uint64_t seed, const mcx_bm_coef& bc, const mcx_bm_vconst* vc = nullptr)
 {
@@ -341,7 +341,7 @@ __device__ __forceinline__ void sim_substep(const KA& k, int step, uint64_t path
 #pragma unroll
         for (int q = 0; q < (NZ + 1) / 2; ++q) {
             double z0, z1;
-            draw_pair<true>(seed, path, (uint32_t)step, (uint32_t)q, ua, z0, z1, tab, bc, vc);
+            draw_pair<true, BMB>(seed, path, (uint32_t)step, (uint32_t)q, ua, z0, z1, tab, bc, vc);
             z[2 * q] = z0;
             if (2 * q + 1 < NZ) z[2 * q + 1] = z1;
         }

@@ -157,28 +157,23 @@ __device__ __forceinline__ double mcx_sqrt_gp(double a)
 // the LDS pipe is otherwise idle in these kernels) shrinks the argument range by 2^7, so a degree-7 log1p and degree-6/7
 // sin/cos corrections are enough: ~16 + ~19 VALU instructions.  Absolute accuracy ~1e-16 (a few ulp of the RESULT away from
 // the table nodes); log(u) keeps full relative accuracy as u -> 1 because the last node is exactly c = 1.
-// MCX_BM_BITS (per translation unit): log2 of the table size.  7 (4 KiB of LDS per block) everywhere but in the one-launch
-// kernel (kf_lean.hip), which runs four blocks per CU and spends 10 (32 KiB) to drop two terms of the log1p polynomial and
-// one of each trigonometric correction: |t| <= 2^-11, |d| <= pi/1024.
+// BMB (template parameter of the table-driven functions): log2 of the table size.  7 (4 KiB of LDS per block) everywhere but in
+// the one-launch kernel of the two-factor rates/credit configuration (kf_lean.hip), which runs four blocks per CU and spends 10
+// (32 KiB) to drop two terms of the log1p polynomial and one of each trigonometric correction: |t| <= 2^-11, |d| <= pi/1024.
 #include "mcx_tables.h"
-#ifndef MCX_BM_BITS
-#define MCX_BM_BITS 7
-#endif
-#define MCX_BM_N (1 << MCX_BM_BITS)
-#define MCX_BM_LDS_DOUBLES (4 * MCX_BM_N)
-#if MCX_BM_BITS == 7
-#define MCX_BM_LOG_SRC MCX_LOG_TAB
-#define MCX_BM_TRIG_SRC MCX_TRIG_TAB
-#define MCX_BM_LOG_TERMS 6
-#define MCX_BM_TRIG_TERMS 3
-#elif MCX_BM_BITS == 10
-#define MCX_BM_LOG_SRC MCX_LOG_TAB_L
-#define MCX_BM_TRIG_SRC MCX_TRIG_TAB_L
-#define MCX_BM_LOG_TERMS 4
-#define MCX_BM_TRIG_TERMS 2
-#else
-#error "MCX_BM_BITS must be 7 or 10"
-#endif
+#define MCX_BM_LDS_DOUBLES_B(BMB) (4 << (BMB))
+#define MCX_BM_LDS_DOUBLES MCX_BM_LDS_DOUBLES_B(7)
+template <int BMB> struct mcx_bm_shape;
+template <> struct mcx_bm_shape<7> {
+    static constexpr int LOG_TERMS = 6, TRIG_TERMS = 3;
+    static __device__ __forceinline__ double log_src(int q) { return MCX_LOG_TAB[q]; }
+    static __device__ __forceinline__ double trig_src(int q) { return MCX_TRIG_TAB[q]; }
+};
+template <> struct mcx_bm_shape<10> {
+    static constexpr int LOG_TERMS = 4, TRIG_TERMS = 2;
+    static __device__ __forceinline__ double log_src(int q) { return MCX_LOG_TAB_L[q]; }
+    static __device__ __forceinline__ double trig_src(int q) { return MCX_TRIG_TAB_L[q]; }
+};
 
 // [0..5] -2 log1p(t) = s + s^2 (c0 + c1 s + ...), s = -2 t: the coefficients of log1p scaled by exact powers of two
 // (c_k' = -c_k (-1/2)^k / 2), so the result is bit for bit -2 x (t + t^2 (-1/2 + t/3 - ...));
@@ -199,29 +194,33 @@ __device__ __forceinline__ mcx_bm_coef mcx_bm_coef_load(int z = 0)      // 24 SG
 struct mcx_bm_vconst {
     double c54;            // 2^-54 (VGPR)
     double s53, s32;       // 2^-53, 2^-32 (SGPR)
-    double log_head;       // C.c[MCX_BM_LOG_TERMS - 1] (VGPR)
+    double log_head;       // leading coefficient of the log1p polynomial (VGPR)
     double sin_head, cos_head;   // leading coefficients of the sin / cos corrections (VGPR)
     double trig_off;       // -pi / N (VGPR)
 };
 __device__ __forceinline__ double mcx_opaque_v(double x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ double mcx_opaque_s(double x) { asm volatile("" : "+s"(x)); return x; }
+template <int BMB = 7>
 __device__ __forceinline__ mcx_bm_vconst mcx_bm_vconst_make(const mcx_bm_coef& C)
 {
+    using SH = mcx_bm_shape<BMB>;
     mcx_bm_vconst v;
     v.c54 = mcx_opaque_v(0x1.0p-54); v.s53 = mcx_opaque_s(0x1.0p-53); v.s32 = mcx_opaque_s(0x1.0p-32);
-    v.log_head = mcx_opaque_v(C.c[MCX_BM_LOG_TERMS - 1]);
-    v.sin_head = mcx_opaque_v(C.c[5 + MCX_BM_TRIG_TERMS]);
-    v.cos_head = mcx_opaque_v(C.c[8 + MCX_BM_TRIG_TERMS]);
-    v.trig_off = mcx_opaque_v(-3.14159265358979323846 / (double)MCX_BM_N);
+    v.log_head = mcx_opaque_v(C.c[SH::LOG_TERMS - 1]);
+    v.sin_head = mcx_opaque_v(C.c[5 + SH::TRIG_TERMS]);
+    v.cos_head = mcx_opaque_v(C.c[8 + SH::TRIG_TERMS]);
+    v.trig_off = mcx_opaque_v(-3.14159265358979323846 / (double)(1 << BMB));
     return v;
 }
 
-// cooperative copy of both tables into the block's LDS area (MCX_BM_LDS_DOUBLES doubles); includes the barrier
+// cooperative copy of both tables into the block's LDS area (MCX_BM_LDS_DOUBLES_B(BMB) doubles); includes the barrier
+template <int BMB = 7>
 __device__ __forceinline__ void mcx_bm_load(double* __restrict__ tab)
 {
-    for (int q = threadIdx.x; q < 2 * MCX_BM_N; q += blockDim.x) {
-        tab[q] = -2.0 * MCX_BM_LOG_SRC[q];         // (-2 / c, -2 log c): the radius needs -2 log u (exact scaling)
-        tab[2 * MCX_BM_N + q] = MCX_BM_TRIG_SRC[q];
+    constexpr int N = 1 << BMB;
+    for (int q = threadIdx.x; q < 2 * N; q += blockDim.x) {
+        tab[q] = -2.0 * mcx_bm_shape<BMB>::log_src(q);        // (-2 / c, -2 log c): the radius needs -2 log u (exact scaling)
+        tab[2 * N + q] = mcx_bm_shape<BMB>::trig_src(q);
     }
     __syncthreads();
 }
@@ -230,16 +229,18 @@ typedef double mcx_d2 __attribute__((ext_vector_type(2)));
 
 // -2 log(x), x a normal double in (0, 1]: the squared Box-Muller radius.  Every constant of log(x) = k ln2 + log c + log1p(m/c - 1)
 // carries the factor -2 (table, ln2 split, polynomial: all exact power-of-two scalings), so the product -2 * log costs nothing
+template <int BMB = 7>
 __device__ __forceinline__ double mcx_m2log_tab(double x, const double* __restrict__ tab, const mcx_bm_coef& C, const mcx_bm_vconst* vc = nullptr)
 {
+    constexpr int N = 1 << BMB, LOG_TERMS = mcx_bm_shape<BMB>::LOG_TERMS;
     const double m = __builtin_amdgcn_frexp_mant(x);                  // [0.5, 1)
     const int e = __builtin_amdgcn_frexp_exp(x);
-    const int j = (__double2hiint(m) >> (20 - MCX_BM_BITS)) & (MCX_BM_N - 1);      // top mantissa bits
+    const int j = (__double2hiint(m) >> (20 - BMB)) & (N - 1);        // top mantissa bits
     const mcx_d2 tc = ((const mcx_d2*)tab)[j];                        // (-2/c, -2 log c)
-    const double s = fma(m, tc.x, 2.0);                                // -2 t, |t| <= 2^-(BITS+1)
-    double q = vc ? vc->log_head : C.c[MCX_BM_LOG_TERMS - 1];
+    const double s = fma(m, tc.x, 2.0);                                // -2 t, |t| <= 2^-(BMB+1)
+    double q = vc ? vc->log_head : C.c[LOG_TERMS - 1];
 #pragma unroll
-    for (int k = MCX_BM_LOG_TERMS - 2; k >= 0; --k) q = fma(q, s, C.c[k]);
+    for (int k = LOG_TERMS - 2; k >= 0; --k) q = fma(q, s, C.c[k]);
     const double p = fma(s * s, q, s);                                 // -2 log1p(t)
     // -2 (e ln2 + log c) + p.  One constant for ln2: the rounding error of e * ln2 is <= 2^-54 of the RESULT (>= 2 |e| ln2 / 2), the
     // accuracy the squared radius needs (a hi / lo split would only matter for log itself near x = 1, where e = 0 anyway)
@@ -249,19 +250,22 @@ __device__ __forceinline__ double mcx_m2log_tab(double x, const double* __restri
 // (sin, cos)(2 pi u) from the cell index j = floor(u N) and the remainder ur = u - j / N in (0, 1/N) — both read off the integer
 // image of the 53-bit uniform by the caller (draw_pair: a shift and a mask instead of scaling, rounding and converting u).
 // The table nodes sit at the cell centres, angle 2 pi (j + 1/2) / N: |d| <= pi / N.
+template <int BMB = 7>
 __device__ __forceinline__ void mcx_sincos2pi_tab(double ur, int j, const double* __restrict__ tab, double& s, double& c, const mcx_bm_coef& C,
                                                   const mcx_bm_vconst* vc = nullptr)
 {
-    const double d = fma(ur, 6.28318530717958647692, vc ? vc->trig_off : -3.14159265358979323846 / (double)MCX_BM_N);
-    const mcx_d2 sc = ((const mcx_d2*)(tab + 2 * MCX_BM_N))[j];
+    constexpr int N = 1 << BMB;
+    const double d = fma(ur, 6.28318530717958647692, vc ? vc->trig_off : -3.14159265358979323846 / (double)N);
+    const mcx_d2 sc = ((const mcx_d2*)(tab + 2 * N))[j];
     const double d2 = d * d;
-#if MCX_BM_TRIG_TERMS == 3
-    const double qs = fma(fma(vc ? vc->sin_head : C.c[8], d2, C.c[7]), d2, C.c[6]);
-    const double qc = fma(fma(vc ? vc->cos_head : C.c[11], d2, C.c[10]), d2, C.c[9]);
-#else
-    const double qs = fma(vc ? vc->sin_head : C.c[7], d2, C.c[6]);
-    const double qc = fma(vc ? vc->cos_head : C.c[10], d2, C.c[9]);
-#endif
+    double qs, qc;
+    if constexpr (mcx_bm_shape<BMB>::TRIG_TERMS == 3) {
+        qs = fma(fma(vc ? vc->sin_head : C.c[8], d2, C.c[7]), d2, C.c[6]);
+        qc = fma(fma(vc ? vc->cos_head : C.c[11], d2, C.c[10]), d2, C.c[9]);
+    } else {
+        qs = fma(vc ? vc->sin_head : C.c[7], d2, C.c[6]);
+        qc = fma(vc ? vc->cos_head : C.c[10], d2, C.c[9]);
+    }
     const double ps = fma(d * d2, qs, d);                              // sin d
     const double pc = fma(d2, qc, 1.0);                                // cos d
     s = fma(sc.x, pc, sc.y * ps);
