@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MCX_ABI_VERSION 3   /* 3: mcx_rng_draws, mcx_comm_* (RCCL), interpolated collateral; 2: batched LSM, tangent-book kernels, bridge RNG */
+#define MCX_ABI_VERSION 4   /* 4: mcx_unsecured_desc.n_rows, mcx_lsm_step_batch w_len (host-side bounds of every row / offset a kernel reads); 3: mcx_rng_draws, mcx_comm_* (RCCL), interpolated collateral; 2: batched LSM, tangent-book kernels, bridge RNG */
 
 #define MCX_MAX_SLOTS   8    /* sub-models in one ModelConfig                                  */
 #define MCX_MAX_Z       8    /* total simulation dimension (correlated normals per sub-step)    */
@@ -206,6 +206,9 @@ typedef struct {
     double  threshold;
     const int32_t* row;         /* [n_dates] row of the netting set's exposure block          */
     const int32_t* delayed;     /* [n_dates] delayed row or -1 (NULL if not collateralised)   */
+    int32_t n_rows;             /* rows of the exposure block handed to the call ([n_rows][ld]): every row / delayed index is
+                                   checked against it on the host                              */
+    int32_t reserved;
 } mcx_unsecured_desc;
 
 /* accumulator record written by every reduction: sums of (x - shift) over the local paths */
@@ -425,8 +428,8 @@ typedef struct {
     double  shift, scale;
 } mcx_lsm_job;
 int  mcx_lsm_step_batch(mcx_handle* h, const mcx_book* book, const mcx_lsm_job* h_jobs, int32_t n_jobs, int32_t n_states,
-                        const double* d_paths, int64_t n_paths, int64_t ld, double* d_W, int64_t ld_w,
-                        double* h_moments, int32_t flags, void* stream);
+                        const double* d_paths, int64_t n_paths, int64_t ld, double* d_W, int64_t ld_w, int64_t w_len,
+                        double* h_moments, int32_t flags, void* stream);     /* w_len: doubles in d_W (bounds of w_offset) */
 /* coeffs[h_offsets[j] + q] = h_values[j * len + q], q < len, for n blocks in one call (the batched form of mcx_book_set_coeffs) */
 int  mcx_book_set_coeffs_batch(mcx_handle* h, mcx_book* book, const int64_t* h_offsets, int32_t n, int32_t len,
                                const double* h_values, void* stream);

@@ -599,7 +599,7 @@ extern "C" int mcx_lsm_run(mcx_handle* h, mcx_book* b, int32_t product, const mc
 }
 
 extern "C" int mcx_lsm_step_batch(mcx_handle* h, const mcx_book* b, const mcx_lsm_job* h_jobs, int32_t n_jobs, int32_t n_states,
-                                  const double* d_paths, int64_t n_paths, int64_t ld, double* d_W, int64_t ld_w,
+                                  const double* d_paths, int64_t n_paths, int64_t ld, double* d_W, int64_t ld_w, int64_t w_len,
                                   double* h_moments, int32_t flags, void* stream)
 {
     if (!h || !b || !h_jobs || !d_paths || !d_W || !h_moments) return -1;
@@ -619,7 +619,7 @@ extern "C" int mcx_lsm_step_batch(mcx_handle* h, const mcx_book* b, const mcx_ls
         if (pr.n_states != S) MCX_FAIL(h, -2, "mcx_lsm_step_batch: job %d has %d states, the batch %d", j, pr.n_states, S);
         if (q.roll_begin < 0 || q.roll_end < q.roll_begin || q.roll_end > pr.cf_end - pr.cf_begin) MCX_FAIL(h, -2, "mcx_lsm_step_batch: job %d roll window", j);
         if (q.num_atom < 0 || q.num_atom >= b->n_atoms || q.x_atom < 0 || q.x_atom >= b->n_atoms) MCX_FAIL(h, -2, "mcx_lsm_step_batch: job %d atoms", j);
-        if (q.w_offset < 0) MCX_FAIL(h, -2, "mcx_lsm_step_batch: job %d cache offset", j);
+        if (q.w_offset < 0 || q.w_offset + (int64_t)S * ld_w > w_len) MCX_FAIL(h, -2, "mcx_lsm_step_batch: job %d cache block outside d_W", j);
         K3Job& o = jobs[j];
         o.ev_off = pr.cf_begin; o.roll_begin = q.roll_begin; o.roll_end = q.roll_end; o.pad = 0; o.w_off = q.w_offset;
         o.shift = q.shift; o.scale = q.scale; o.num = flat(q.num_atom); o.x = flat(q.x_atom);

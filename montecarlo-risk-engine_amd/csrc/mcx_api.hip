@@ -282,6 +282,12 @@ void* mcx_stage_small(mcx_handle* h, const void* src, size_t bytes, hipStream_t 
 int mcx_upload_unsec(mcx_handle* h, const mcx_unsecured_desc* u, DevUnsec* out, int32_t** d_tmp, hipStream_t s)
 {
     if (u->n_dates < 1 || u->n_dates > MCX_MAX_METRIC_DATES) MCX_FAIL(h, -2, "unsecured desc: n_dates %d out of range", u->n_dates);
+    if (u->n_rows < 1 || !u->row) MCX_FAIL(h, -2, "unsecured desc: n_rows %d / row table missing", u->n_rows);
+    for (int m = 0; m < u->n_dates; ++m) {                          // the kernels index the exposure block with these
+        if (u->row[m] < 0 || u->row[m] >= u->n_rows) MCX_FAIL(h, -2, "unsecured desc: row[%d] = %d outside the %d exposure rows", m, u->row[m], u->n_rows);
+        if (u->delayed && (u->delayed[m] < -1 || u->delayed[m] >= u->n_rows))
+            MCX_FAIL(h, -2, "unsecured desc: delayed[%d] = %d outside the %d exposure rows", m, u->delayed[m], u->n_rows);
+    }
     *d_tmp = nullptr;                                               // (nothing to free: the tables live in the staging ring)
     const int32_t* d_row = (const int32_t*)mcx_stage_small(h, u->row, sizeof(int32_t) * u->n_dates, s);
     if (!d_row) return -100;

@@ -5,7 +5,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_SLOTS = 8
 MAX_Z = 8
 MAX_STATE = 16
@@ -58,7 +58,7 @@ class BookDesc(C.Structure):
 
 class UnsecuredDesc(C.Structure):
     _fields_ = [("n_dates", C.c_int32), ("collateralized", C.c_int32), ("threshold", C.c_double),
-                ("row", C.c_void_p), ("delayed", C.c_void_p)]
+                ("row", C.c_void_p), ("delayed", C.c_void_p), ("n_rows", C.c_int32), ("reserved", C.c_int32)]
 
 
 class FusedNsDesc(C.Structure):

@@ -419,7 +419,7 @@ class HipBackend:
         out = np.zeros((len(jobs), (2 * K - 1) + n_states * K))
         self._check(self.lib.mcx_lsm_step_batch(
             self.h, book.ptr, _abi.ptr(jobs), C.c_int32(len(jobs)), C.c_int32(n_states), _vp(paths.data_ptr()), C.c_int64(n),
-            C.c_int64(n), _vp(W.data_ptr()), C.c_int64(ld_w), _abi.ptr(out), C.c_int32(int(flags)), self._stream()),
+            C.c_int64(n), _vp(W.data_ptr()), C.c_int64(ld_w), C.c_int64(W.numel()), _abi.ptr(out), C.c_int32(int(flags)), self._stream()),
             "mcx_lsm_step_batch")
         return out
 
@@ -439,6 +439,7 @@ class HipBackend:
 
     def reduce_profiles(self, unsec, expo_ns: torch.Tensor) -> np.ndarray:
         n = expo_ns.shape[1]
+        unsec.desc.n_rows = expo_ns.shape[0]           # the library checks every row / delayed index against the block it is given
         out = np.zeros((unsec.n_dates, 2), dtype=_abi.ACC_DTYPE)
         self._check(self.lib.mcx_reduce_profiles(self.h, C.byref(unsec.desc), _vp(expo_ns.data_ptr()), C.c_int64(n),
                                                  C.c_int64(n), _abi.ptr(out), self._stream()), "mcx_reduce_profiles")
@@ -447,6 +448,7 @@ class HipBackend:
     def reduce_cva(self, book, unsec, surv_atoms, cond_atoms, recovery: float, expo_ns: torch.Tensor,
                    paths: torch.Tensor) -> np.ndarray:
         n = expo_ns.shape[1]
+        unsec.desc.n_rows = expo_ns.shape[0]
         sa = np.ascontiguousarray(surv_atoms, dtype=np.int32)
         ca = np.ascontiguousarray(cond_atoms, dtype=np.int32)
         out = np.zeros(1, dtype=_abi.ACC_DTYPE)
@@ -458,6 +460,7 @@ class HipBackend:
 
     def unsecured(self, unsec, expo_ns: torch.Tensor) -> torch.Tensor:
         n = expo_ns.shape[1]
+        unsec.desc.n_rows = expo_ns.shape[0]
         out = self.empty(unsec.n_dates, n)
         self._check(self.lib.mcx_unsecured(self.h, C.byref(unsec.desc), _vp(expo_ns.data_ptr()), C.c_int64(n),
                                            C.c_int64(n), _vp(out.data_ptr()), C.c_int64(n), self._stream()),
@@ -466,6 +469,7 @@ class HipBackend:
 
     def select_hist(self, unsec, expo_ns: torch.Tensor, n_sel: int, prefix: np.ndarray, shift: int, bits: int) -> torch.Tensor:
         n = expo_ns.shape[1]
+        unsec.desc.n_rows = expo_ns.shape[0]
         pf = np.ascontiguousarray(prefix, dtype=np.uint64)
         hist = self.empty(unsec.n_dates, n_sel, 1 << bits, dtype=torch.int64)
         self._check(self.lib.mcx_select_hist(self.h, C.byref(unsec.desc), _vp(expo_ns.data_ptr()), C.c_int64(n),

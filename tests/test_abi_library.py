@@ -19,7 +19,7 @@ def test_header_symbols_are_exported():
     assert len(syms) >= 19
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/mcx.h but not exported"
-    assert lib.mcx_abi_version() == 3
+    assert lib.mcx_abi_version() == 4
     assert set(_native._EXPORTS) == set(syms)
 
 
@@ -29,7 +29,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_abi.Slot) == 16 + 8 * _abi.SLOT_NPARAM
     assert ctypes.sizeof(_abi.SimDesc) == 40 + 8 * ctypes.sizeof(_abi.Slot) + 4 * 8
     assert ctypes.sizeof(_abi.BookDesc) == 12 * 4 + 5 * 8
-    assert ctypes.sizeof(_abi.UnsecuredDesc) == 8 + 8 + 16
+    assert ctypes.sizeof(_abi.UnsecuredDesc) == 8 + 8 + 16 + 8
 
 
 def test_product_fails_loudly_without_gpu():

@@ -89,3 +89,48 @@ def test_monte_carlo_second_order_derivatives_converge_to_the_black_scholes_hess
     assert abs(H["spot"]["volatility"] - (-norm.pdf(d1) * d2 / sig)) < 0.08 * abs(norm.pdf(d1) * d2 / sig)
     assert abs(H["spot"]["volatility"] - H["volatility"]["spot"]) < 0.08 * abs(H["spot"]["volatility"])          # symmetric up to noise
     assert res.get_derivatives(0, "pv", evaluation_idx=0)["spot"] == pytest.approx(0.875, abs=0.01)
+
+
+@pytest.mark.gpu
+def test_library_rejects_indices_a_kernel_would_read_out_of_bounds(hip):
+    """every row / date / offset a kernel dereferences is checked on the host (a wild index on the GPU can take the node down):
+    exposure rows of the metric descriptors, atom dates of a book, cashflow-cache offsets of the batched LSM step"""
+    import torch
+    from mcx.plan import UnsecuredSpec
+    E, n = 5, 4096
+    expo = torch.zeros(E, n, dtype=torch.float64, device=hip.device)
+    ok = hip.reduce_profiles(UnsecuredSpec(np.arange(E), None, 0.0, False), expo)
+    assert ok.shape[0] == E
+    for rows, delayed in ((np.array([0, 1, E]), None), (np.array([0, -1, 2]), None), (np.arange(3), np.array([-1, 0, E])),
+                          (np.arange(3), np.array([-2, 0, 1]))):
+        spec = UnsecuredSpec(rows, delayed, 0.0, delayed is not None)
+        with pytest.raises(RuntimeError, match="outside the"):
+            hip.reduce_profiles(spec, expo)
+        with pytest.raises(RuntimeError, match="outside the"):
+            hip.unsecured(spec, expo)
+        with pytest.raises(RuntimeError, match="outside the"):
+            hip.select_hist(spec, expo, 1, np.zeros((len(rows), 1), dtype=np.uint64), 53, 11)
+    # a book whose atom reads a date the paths tensor does not have
+    sc, _ = cases.make_controller("irs_cva", hip, inject=False)
+    sc.prepare()
+    plan = sc.book_plan
+    saved = plan.atoms["t_idx"].copy()
+    plan.atoms["t_idx"][0] = plan.desc.n_dates
+    try:
+        with pytest.raises(RuntimeError):
+            hip.book_create(plan)
+    finally:
+        plan.atoms["t_idx"][:] = saved
+    # batched LSM step: a cashflow-cache block that ends beyond the cache tensor
+    from mcx import _abi
+    jobs = np.zeros(1, dtype=_abi.LSM_JOB_DTYPE)
+    jobs["product"], jobs["roll_begin"], jobs["roll_end"] = 0, 0, 0
+    jobs["num_atom"], jobs["x_atom"] = 0, 0
+    paths = sc.last_state.get("paths_pre")
+    if paths is None:
+        paths = torch.zeros(sc.sim_plan.n_dates, sc.sim_plan.n_state, 1024, dtype=torch.float64, device=hip.device)
+    npre = paths.shape[2]
+    W = torch.zeros(npre, dtype=torch.float64, device=hip.device)
+    jobs["w_offset"] = 1
+    with pytest.raises(RuntimeError, match="outside d_W"):
+        hip.lsm_step_batch(sc.book, jobs, 1, paths, W, npre)
