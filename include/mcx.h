@@ -282,6 +282,11 @@ int  mcx_generate_paths_from_state(mcx_handle* h, const mcx_sim* sim, uint64_t s
  * d_z [2][n] = the Box-Muller pair computed exactly as in the kernels (table-driven log / sincos).  Each output is nullable. */
 int  mcx_rng_draws(mcx_handle* h, uint64_t seed, uint64_t path0, int64_t n, uint32_t step, uint32_t draw,
                    uint32_t* d_words, double* d_u, double* d_z, void* stream);
+/* The map from the four words of a Philox block to the two uniforms and the Box-Muller pair, exactly as the path kernels apply
+ * it (d_words [4][n] -> d_u [2][n] (nullable), d_z [2][n]); table_bits = 7: the 128-entry tables of the path kernels, 10: the
+ * 1024-entry tables of the one-launch kernel of the two-factor configuration.  For tests: edge words (all ones: u rounds to 1 and
+ * the pair is (0, 0)), table-cell boundaries, random words against a libm evaluation. */
+int  mcx_box_muller(mcx_handle* h, const uint32_t* d_words, int64_t n, int32_t table_bits, double* d_u, double* d_z, void* stream);
 
 /* K2 — replaces RequestInterface.resolve_requests + SimulationController._evaluate_product summed per netting set
  * (controller/controller.py:385-471, 584-591). d_cfs [n_netting_sets][ld_out], d_expo [n_netting_sets][n_expo_rows][ld_out]. */

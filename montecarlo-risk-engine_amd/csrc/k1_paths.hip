@@ -92,7 +92,37 @@ __global__ __launch_bounds__(MCX_BLOCK) void k1_rng_draws(uint64_t seed, uint64_
     }
 }
 
+// words [4][n] of Philox blocks -> uniforms [2][n] and Box-Muller pairs [2][n], with the BMB-bit tables
+template <int BMB>
+__global__ __launch_bounds__(MCX_BLOCK) void k1_box_muller(const uint32_t* __restrict__ words, int64_t n, double* __restrict__ u,
+                                                          double* __restrict__ z)
+{
+    __shared__ double bm_lds[MCX_BM_LDS_DOUBLES_B(BMB)];
+    mcx_bm_load<BMB>(bm_lds);
+    const mcx_bm_coef bc = mcx_bm_coef_load();
+    const mcx_bm_vconst vc = mcx_bm_vconst_make<BMB>(bc);
+    for (int64_t i = (int64_t)blockIdx.x * MCX_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * MCX_BLOCK) {
+        const uint32_t w0 = words[i], w1 = words[n + i], w2 = words[2 * n + i], w3 = words[3 * n + i];
+        double ua, z0, z1;
+        pair_from_words<true, BMB>(w0, w1, w2, w3, ua, z0, z1, bm_lds, bc, &vc);
+        if (u) { u[i] = ua; u[n + i] = u53(w2, w3); }
+        z[i] = z0; z[n + i] = z1;
+    }
+}
+
 }  // namespace
+
+extern "C" int mcx_box_muller(mcx_handle* h, const uint32_t* d_words, int64_t n, int32_t table_bits, double* d_u, double* d_z, void* stream)
+{
+    if (!h || !d_words || !d_z) return -1;
+    if (table_bits != 7 && table_bits != 10) MCX_FAIL(h, -2, "mcx_box_muller: table_bits must be 7 or 10");
+    if (n <= 0) return 0;
+    const int grid = mcx_grid_for(n, MCX_BLOCK, 2048);
+    if (table_bits == 7) hipLaunchKernelGGL(k1_box_muller<7>, dim3(grid), dim3(MCX_BLOCK), 0, (hipStream_t)stream, d_words, n, d_u, d_z);
+    else hipLaunchKernelGGL(k1_box_muller<10>, dim3(grid), dim3(MCX_BLOCK), 0, (hipStream_t)stream, d_words, n, d_u, d_z);
+    MCX_HIP(h, hipGetLastError());
+    return 0;
+}
 
 extern "C" int mcx_rng_draws(mcx_handle* h, uint64_t seed, uint64_t path0, int64_t n, uint32_t step, uint32_t draw,
                              uint32_t* d_words, double* d_u, double* d_z, void* stream)

@@ -124,16 +124,21 @@ __device__ __forceinline__ double dev_barrier_event(const DevEvent& e, const Dev
 
 // one draw = two uniforms in (0,1) and their Box-Muller pair (include/mcx.h "RNG contract")
 // TAB: `tab` is the block's LDS copy of the Box-Muller tables (mcx_bm_load); otherwise polynomial log / sincos
+// the four words of one Philox block -> first uniform + Box-Muller pair (what mcx_box_muller exposes for tests)
 template <bool TAB = false, int BMB = 7>
-__device__ __forceinline__ void draw_pair(uint64_t seed, uint64_t path, uint32_t step, uint32_t draw, double& ua, double& z0, double& z1,
-                                          const double* __restrict__ tab, const mcx_bm_coef& bc, const mcx_bm_vconst* vc = nullptr)
+__device__ __forceinline__ void pair_from_words(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, double& ua, double& z0, double& z1,
+                                                const double* __restrict__ tab, const mcx_bm_coef& bc, const mcx_bm_vconst* vc = nullptr)
 {
-    uint32_t w0, w1, w2, w3;
-    philox4x32_10((uint32_t)path, (uint32_t)(path >> 32), step, draw, (uint32_t)seed, (uint32_t)(seed >> 32), w0, w1, w2, w3);
     ua = u53(w0, w1, vc);
     double s, c, r;
     if (TAB) {
-        r = mcx_sqrt_gp(mcx_m2log_tab<BMB>(ua, tab, bc, vc));      // u < 1: the squared radius is > 0
+        // The squared radius -2 log u is > 0 for every u < 1, and the root then needs no zero test.  One draw in 2^53 rounds to
+        // u = 1 exactly ((2^53 - 1/2) 2^-53, a tie): its radius is 0 (as on the CPU path), where the table evaluation leaves a
+        // rounding residual of either sign and the unguarded root may return NaN.  u = 1 needs the high word all ones: a wave that
+        // holds such a lane (one in 10^8 wave-steps) takes the guarded path; the common path pays one integer compare.
+        const double r2 = mcx_m2log_tab<BMB>(ua, tab, bc, vc);
+        if (__builtin_expect(__any(w1 == 0xffffffffu), 0)) r = ua < 1.0 ? mcx_sqrt_g(r2) : 0.0;
+        else r = mcx_sqrt_gp(r2);
         // second uniform u = ((x >> 11) + 0.5) 2^-53, x = w3:w2: its top BMB bits are the table cell, the rest is u - j/N
         // (the same conversion on the masked word, exact)
         const int j = (int)(w3 >> (32 - BMB));
@@ -145,6 +150,15 @@ __device__ __forceinline__ void draw_pair(uint64_t seed, uint64_t path, uint32_t
     }
     z0 = r * c;
     z1 = r * s;
+}
+
+template <bool TAB = false, int BMB = 7>
+__device__ __forceinline__ void draw_pair(uint64_t seed, uint64_t path, uint32_t step, uint32_t draw, double& ua, double& z0, double& z1,
+                                          const double* __restrict__ tab, const mcx_bm_coef& bc, const mcx_bm_vconst* vc = nullptr)
+{
+    uint32_t w0, w1, w2, w3;
+    philox4x32_10((uint32_t)path, (uint32_t)(path >> 32), step, draw, (uint32_t)seed, (uint32_t)(seed >> 32), w0, w1, w2, w3);
+    pair_from_words<TAB, BMB>(w0, w1, w2, w3, ua, z0, z1, tab, bc, vc);
 }
 
 template <bool TAB = false>

@@ -24,7 +24,7 @@ _EXPORTS = [
     "mcx_book_create", "mcx_book_destroy", "mcx_book_set_coeffs", "mcx_eval_book", "mcx_resolve_atoms",
     "mcx_lsm_stats", "mcx_lsm_step", "mcx_lsm_run", "mcx_lsm_step_batch", "mcx_book_set_coeffs_batch", "mcx_book_set_bridge_rng", "mcx_book_set_exercise_replay",
     "mcx_fused_is_straight_line", "mcx_tangent_paths", "mcx_tangent_lsm", "mcx_tangent_eval", "mcx_tangent_cva", "mcx_tangent_profiles", "mcx_tangent_pick",
-    "mcx_tangent_european", "mcx_fused_create", "mcx_fused_destroy", "mcx_fused_num_records", "mcx_fused_run", "mcx_fused_eval_paths", "mcx_fused_run_device", "mcx_fused_eval_paths_device",
+    "mcx_box_muller", "mcx_tangent_european", "mcx_fused_create", "mcx_fused_destroy", "mcx_fused_num_records", "mcx_fused_run", "mcx_fused_eval_paths", "mcx_fused_run_device", "mcx_fused_eval_paths_device",
     "mcx_reduce_vector", "mcx_reduce_profiles", "mcx_reduce_cva", "mcx_unsecured", "mcx_select_hist",
 ]
 
@@ -264,6 +264,14 @@ class HipBackend:
             self.h, fused.ptr, C.c_uint64(seed), C.c_uint64(path_offset), C.c_int64(n_paths), dp(paths), C.c_int64(n_paths),
             dp(cfs), dp(expo), C.c_int64(n_paths), dp(inject_z), dp(inject_u), _abi.ptr(out), self._stream()), "mcx_fused_run")
         return out
+
+    def box_muller(self, words: torch.Tensor, table_bits: int = 7):
+        """words: int32/uint32 device tensor [4][n] of Philox output blocks -> (uniforms [2][n], normals [2][n]) as the kernels map them"""
+        n = words.shape[1]
+        u, z = self.empty(2, n), self.empty(2, n)
+        self._check(self.lib.mcx_box_muller(self.h, _vp(words.data_ptr()), C.c_int64(n), C.c_int32(table_bits), _vp(u.data_ptr()),
+                                            _vp(z.data_ptr()), self._stream()), "mcx_box_muller")
+        return u, z
 
     def fused_is_straight_line(self, f) -> bool:
         return bool(self.lib.mcx_fused_is_straight_line(f.ptr))

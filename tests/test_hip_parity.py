@@ -88,6 +88,48 @@ def test_philox_paths_through_the_qe_scheme(hip, oracle):
     assert np.allclose(out["hip"], out["oracle"], rtol=1e-11, atol=1e-13)
 
 
+def _oracle_pairs(oracle, words):
+    import ctypes as C
+    n = words.shape[1]
+    u, z = np.zeros((2, n)), np.zeros((2, n))
+    fn = oracle.lib.orc_pair_from_words
+    fn.restype = None
+    a, b, c, d = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+    for i in range(n):
+        w = (C.c_uint32 * 4)(*[int(x) for x in words[:, i]])
+        fn(w, C.byref(a), C.byref(b), C.byref(c), C.byref(d))
+        u[:, i] = a.value, b.value
+        z[:, i] = c.value, d.value
+    return u, z
+
+
+@pytest.mark.parametrize("bits", [7, 10])
+def test_box_muller_edge_words_and_table_cells(bits, hip, oracle):
+    """the word -> (uniform, normal pair) map of the kernels (mcx_box_muller) against the oracle's libm evaluation on the words
+    that stress it: all ones (u rounds to 1: radius 0, no NaN from the unguarded root), all zeros (smallest u), the first / last
+    word of table cells of both tables, exponent boundaries of the first uniform, and random words"""
+    rng = np.random.default_rng(99)
+    N = 1 << bits
+    cols = [(0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff), (0xfffff800, 0xffffffff, 0, 0), (0xfffff7ff, 0xffffffff, 1, 0),
+            (0, 0, 0, 0), (0x800, 0, 0x7ff, 0), (0, 1, 0, 1), (0, 0x80000000, 0, 0x80000000), (0xffffffff, 0x7fffffff, 0xffffffff, 0x7fffffff)]
+    for j in (0, 1, N // 2 - 1, N // 2, N - 2, N - 1):                       # trig table cell j: w3 top bits; log cells via u in [0.5, 1)
+        lo_edge, hi_edge = j << (32 - bits), ((j + 1) << (32 - bits)) - 1
+        cols += [(0, 0x80000000 | (lo_edge >> 1), 0, lo_edge), (0xffffffff, 0x80000000 | (hi_edge >> 1), 0xffffffff, hi_edge)]
+    for e in range(1, 54, 4):                                               # first uniform ~ 2^-e
+        hi = (1 << 32) >> e if e <= 32 else 0
+        lo = 0 if e <= 32 else (1 << 64) >> e
+        cols.append((lo & 0xffffffff, hi & 0xffffffff, 12345, 0x9e3779b9))
+    words = np.array(cols, dtype=np.uint64).T
+    words = np.concatenate([words, rng.integers(0, 1 << 32, size=(4, 4096), dtype=np.uint64)], axis=1).astype(np.uint32)
+    u, z = hip.box_muller(torch.from_numpy(words.view(np.int32)).to(hip.device), bits)
+    u, z = u.cpu().numpy(), z.cpu().numpy()
+    uo, zo = _oracle_pairs(oracle, words)
+    assert np.array_equal(u, uo)                                            # bit for bit, including u == 1.0 in column 0 and 1
+    assert u[0, 0] == 1.0 and u[0, 1] == 1.0 and u[0, 2] < 1.0
+    assert np.all(np.isfinite(z)) and z[0, 0] == 0.0 and z[1, 0] == 0.0 and z[0, 1] == 0.0
+    assert np.abs(z - zo).max() < 2e-14, np.abs(z - zo).max()
+
+
 KATS = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),          # Random123 kat_vectors, philox4x32 10
         ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
         ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
