@@ -186,8 +186,13 @@ def main():
     res = None
     # A GPU that sat idle through minutes of imports is in a low power state and needs about a second of load to reach its
     # clocks; W warm-up passes of ~1 ms each do not get it there.  Run the same pass untimed for --clock-warmup seconds first.
-    t_end = time.perf_counter() + args.clock_warmup
-    while time.perf_counter() < t_end:
+    # (a fixed pass count agreed by all ranks: every pass holds a collective, a time-based loop would not match across ranks)
+    n_clock = int(args.clock_warmup / max(plan_ms[best] * 1e-3, 1e-4))
+    if grouped:
+        tc = torch.tensor([n_clock], dtype=torch.int64, device="cuda")
+        dist.broadcast(tc, 0)
+        n_clock = int(tc.item())
+    for _ in range(n_clock):
         sc.main_pass(paths_buf if best != "fused" else None)
     for _ in range(args.warmup):
         res = sc.main_pass(paths_buf if best != "fused" else None)
