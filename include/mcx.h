@@ -478,6 +478,15 @@ int  mcx_unsecured(mcx_handle* h, const mcx_unsecured_desc* u, const double* d_e
 int  mcx_select_hist(mcx_handle* h, const mcx_unsecured_desc* u, const double* d_expo_ns, int64_t n_paths, int64_t ld,
                      int32_t n_sel, const uint64_t* h_prefix, int32_t shift, int32_t bits,
                      uint64_t* d_hist, void* stream);
+/* The same digit pass with the prefixes already on the device, and the step between two passes on the device: from the
+ * (all-reduced) histogram pick, per (date, selection), the bin b holding the remaining rank (d_rem [n_dates][n_sel], starts as the
+ * 0-based global ranks), d_prefix |= b << shift, d_rem -= count below b.  A select is then six (hist, [all-reduce], narrow) pairs
+ * enqueued back to back and ONE copy of the final prefixes (the order statistics as order-preserving uint64 keys): no host round
+ * trip per pass (pfe_metric.py:49-73 sorts N values per date on the host). */
+int  mcx_select_hist_dev(mcx_handle* h, const mcx_unsecured_desc* u, const double* d_expo_ns, int64_t n_paths, int64_t ld,
+                         int32_t n_sel, const uint64_t* d_prefix, int32_t shift, int32_t bits, uint64_t* d_hist, void* stream);
+int  mcx_select_narrow(mcx_handle* h, int32_t n_dates, int32_t n_sel, const uint64_t* d_hist, int32_t shift, int32_t bits,
+                       uint64_t* d_prefix, int64_t* d_rem, void* stream);
 
 /* Multi-GPU exchange (paths shard over the GPUs of a node, one process per GPU; the only data that crosses
  * GPUs are accumulator records, LSM moments and select histograms).  RCCL over xGMI, loaded at run time (librccl.so.1 — the

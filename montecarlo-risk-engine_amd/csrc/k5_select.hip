@@ -84,23 +84,97 @@ __global__ __launch_bounds__(MCX_BLOCK) void k5_hist(const DevUnsec u, const dou
     }
 }
 
+// After a digit pass (and the all-reduce of its histograms over the ranks): per (date, selection) the bin b that holds the
+// remaining rank r — the number of bins whose inclusive cumulative count is <= r — then prefix |= b << shift and
+// r -= (count below bin b).  One block per (date, selection); integer arithmetic only.  Keeps the six passes of a select on the
+// device: the host reads the final prefixes once instead of a histogram per pass.
+__global__ __launch_bounds__(MCX_BLOCK) void k5_narrow(const unsigned long long* __restrict__ hist, int bits, int shift,
+                                                       unsigned long long* __restrict__ prefix, long long* __restrict__ rem)
+{
+    const int nb = 1 << bits, per = (nb + MCX_BLOCK - 1) / MCX_BLOCK;
+    const unsigned long long* h = hist + (int64_t)blockIdx.x * nb;
+    __shared__ long long part[MCX_BLOCK];
+    __shared__ long long red_cnt[MCX_BLOCK], red_below[MCX_BLOCK];
+    const int t = threadIdx.x, b0 = t * per;
+    long long local = 0;
+    for (int q = 0; q < per; ++q) if (b0 + q < nb) local += (long long)h[b0 + q];
+    part[t] = local;
+    __syncthreads();
+    for (int off = 1; off < MCX_BLOCK; off <<= 1) {            // inclusive scan of the 256 partial sums
+        const long long add = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += add;
+        __syncthreads();
+    }
+    long long cum = part[t] - local;                           // count below this thread's first bin
+    const long long r = rem[blockIdx.x];
+    long long cnt = 0, below = 0;
+    for (int q = 0; q < per; ++q) {
+        if (b0 + q >= nb) break;
+        cum += (long long)h[b0 + q];
+        if (cum <= r) { ++cnt; below = cum; }                  // cum is non-decreasing: the last hit is the largest
+    }
+    red_cnt[t] = cnt; red_below[t] = below;
+    __syncthreads();
+    for (int off = MCX_BLOCK / 2; off > 0; off >>= 1) {
+        if (t < off) {
+            red_cnt[t] += red_cnt[t + off];
+            red_below[t] = red_below[t] > red_below[t + off] ? red_below[t] : red_below[t + off];
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        prefix[blockIdx.x] |= (unsigned long long)red_cnt[0] << shift;
+        rem[blockIdx.x] = r - red_below[0];
+    }
+}
+
 }  // namespace
+
+static int select_hist_impl(mcx_handle* h, const mcx_unsecured_desc* u, const double* d_expo_ns, int64_t n_paths, int64_t ld,
+                            int32_t n_sel, const uint64_t* d_prefix, int32_t shift, int32_t bits, uint64_t* d_hist, hipStream_t s);
+
+extern "C" int mcx_select_hist_dev(mcx_handle* h, const mcx_unsecured_desc* u, const double* d_expo_ns, int64_t n_paths, int64_t ld,
+                                   int32_t n_sel, const uint64_t* d_prefix, int32_t shift, int32_t bits, uint64_t* d_hist, void* stream)
+{
+    if (!h || !u || !d_expo_ns || !d_prefix || !d_hist) return -1;
+    return select_hist_impl(h, u, d_expo_ns, n_paths, ld, n_sel, d_prefix, shift, bits, d_hist, (hipStream_t)stream);
+}
+
+extern "C" int mcx_select_narrow(mcx_handle* h, int32_t n_dates, int32_t n_sel, const uint64_t* d_hist, int32_t shift, int32_t bits,
+                                 uint64_t* d_prefix, int64_t* d_rem, void* stream)
+{
+    if (!h || !d_hist || !d_prefix || !d_rem) return -1;
+    if (n_dates < 1 || n_sel < 1 || n_sel > K5_MAX_SEL || bits < 1 || bits > 11 || shift < 0 || shift + bits > 64)
+        MCX_FAIL(h, -2, "mcx_select_narrow: bad selection geometry (n_dates=%d n_sel=%d shift=%d bits=%d)", n_dates, n_sel, shift, bits);
+    hipLaunchKernelGGL(k5_narrow, dim3(n_dates * n_sel), dim3(MCX_BLOCK), 0, (hipStream_t)stream, (const unsigned long long*)d_hist, (int)bits,
+                       (int)shift, (unsigned long long*)d_prefix, (long long*)d_rem);
+    MCX_HIP(h, hipGetLastError());
+    return 0;
+}
 
 extern "C" int mcx_select_hist(mcx_handle* h, const mcx_unsecured_desc* u, const double* d_expo_ns, int64_t n_paths, int64_t ld,
                                int32_t n_sel, const uint64_t* h_prefix, int32_t shift, int32_t bits, uint64_t* d_hist, void* stream)
 {
     if (!h || !u || !d_expo_ns || !h_prefix || !d_hist) return -1;
+    if (n_sel < 1 || n_sel > K5_MAX_SEL || u->n_dates < 1) MCX_FAIL(h, -2, "mcx_select_hist: bad selection geometry (n_sel=%d)", n_sel);
+    hipStream_t s = (hipStream_t)stream;
+    const uint64_t* d_prefix = (const uint64_t*)mcx_stage_small(h, h_prefix, sizeof(uint64_t) * (size_t)u->n_dates * n_sel, s);
+    if (!d_prefix) return -100;
+    return select_hist_impl(h, u, d_expo_ns, n_paths, ld, n_sel, d_prefix, shift, bits, d_hist, s);
+}
+
+static int select_hist_impl(mcx_handle* h, const mcx_unsecured_desc* u, const double* d_expo_ns, int64_t n_paths, int64_t ld,
+                            int32_t n_sel, const uint64_t* d_prefix, int32_t shift, int32_t bits, uint64_t* d_hist, hipStream_t s)
+{
     if (n_sel < 1 || n_sel > K5_MAX_SEL || bits < 1 || bits > 11 || shift < 0 || shift + bits > 64)
         MCX_FAIL(h, -2, "mcx_select_hist: bad selection geometry (n_sel=%d shift=%d bits=%d)", n_sel, shift, bits);
-    hipStream_t s = (hipStream_t)stream;
     const size_t nh = (size_t)u->n_dates * n_sel * ((size_t)1 << bits);
     MCX_HIP(h, hipMemsetAsync(d_hist, 0, nh * sizeof(uint64_t), s));
     if (n_paths <= 0) return 0;
     DevUnsec du; int32_t* tmp = nullptr;
     int rc = mcx_upload_unsec(h, u, &du, &tmp, s);
     if (rc) return rc;
-    const uint64_t* d_prefix = (const uint64_t*)mcx_stage_small(h, h_prefix, sizeof(uint64_t) * (size_t)u->n_dates * n_sel, s);
-    if (!d_prefix) return -100;
     // a block pays a fixed cost (zeroing and scanning its n_sel x 2^bits LDS bins): give it >= 32 elements per thread, and no
     // more blocks than ~16 per CU over all dates
     int gx = mcx_grid_for(n_paths, MCX_BLOCK * 32, (16 * h->n_cu + u->n_dates - 1) / u->n_dates);

@@ -25,7 +25,7 @@ _EXPORTS = [
     "mcx_lsm_stats", "mcx_lsm_step", "mcx_lsm_run", "mcx_lsm_step_batch", "mcx_book_set_coeffs_batch", "mcx_book_set_bridge_rng", "mcx_book_set_exercise_replay",
     "mcx_fused_is_straight_line", "mcx_tangent_paths", "mcx_tangent_lsm", "mcx_tangent_eval", "mcx_tangent_cva", "mcx_tangent_profiles", "mcx_tangent_pick",
     "mcx_box_muller", "mcx_tangent_european", "mcx_fused_create", "mcx_fused_destroy", "mcx_fused_num_records", "mcx_fused_run", "mcx_fused_eval_paths", "mcx_fused_run_device", "mcx_fused_eval_paths_device",
-    "mcx_reduce_vector", "mcx_reduce_profiles", "mcx_reduce_cva", "mcx_unsecured", "mcx_select_hist",
+    "mcx_reduce_vector", "mcx_reduce_profiles", "mcx_reduce_cva", "mcx_unsecured", "mcx_select_hist", "mcx_select_hist_dev", "mcx_select_narrow",
 ]
 
 
@@ -484,6 +484,21 @@ class HipBackend:
                                              C.c_int64(n), C.c_int32(n_sel), _abi.ptr(pf), C.c_int32(shift),
                                              C.c_int32(bits), _vp(hist.data_ptr()), self._stream()), "mcx_select_hist")
         return hist
+
+
+    # device-resident select (no host round trip per digit pass)
+    def select_hist_dev(self, unsec, expo_ns: torch.Tensor, n_sel: int, prefix: torch.Tensor, shift: int, bits: int, out: torch.Tensor):
+        n = expo_ns.shape[1]
+        unsec.desc.n_rows = expo_ns.shape[0]
+        self._check(self.lib.mcx_select_hist_dev(self.h, C.byref(unsec.desc), _vp(expo_ns.data_ptr()), C.c_int64(n), C.c_int64(n),
+                                                 C.c_int32(n_sel), _vp(prefix.data_ptr()), C.c_int32(shift), C.c_int32(bits),
+                                                 _vp(out.data_ptr()), self._stream()), "mcx_select_hist_dev")
+        return out
+
+    def select_narrow(self, hist: torch.Tensor, n_dates: int, n_sel: int, shift: int, bits: int, prefix: torch.Tensor, rem: torch.Tensor):
+        self._check(self.lib.mcx_select_narrow(self.h, C.c_int32(n_dates), C.c_int32(n_sel), _vp(hist.data_ptr()), C.c_int32(shift),
+                                               C.c_int32(bits), _vp(prefix.data_ptr()), _vp(rem.data_ptr()), self._stream()),
+                    "mcx_select_narrow")
 
 
 class _Owned:

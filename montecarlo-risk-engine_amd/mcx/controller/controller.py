@@ -555,6 +555,18 @@ class SimulationController:
         """exact global order statistics x_(r) for r in ranks at every metric date -> [n_dates][len(ranks)]"""
         be = self.backend
         E, n_sel = unsec.n_dates, len(ranks)
+        if hasattr(be, "select_narrow"):
+            # the six digit passes enqueued back to back: histogram, all-reduce over the ranks (stream-ordered), bin selection on
+            # the device; ONE copy of the final keys (a host round trip per pass is six stalls of the stream)
+            prefix = be.zeros(E, n_sel, dtype=torch.int64)
+            rem = be.from_numpy(np.tile(np.asarray(ranks, dtype=np.int64), (E, 1)))
+            buf = self._buffer_typed("select_hist", torch.int64, E * n_sel * (1 << max(b for _, b in _SELECT_DIGITS)))
+            for shift, bits in _SELECT_DIGITS:
+                hist = buf[:E * n_sel * (1 << bits)].view(E, n_sel, 1 << bits)
+                be.select_hist_dev(unsec, expo_ns, n_sel, prefix, shift, bits, hist)
+                shard.all_reduce_(hist)
+                be.select_narrow(hist, E, n_sel, shift, bits, prefix, rem)
+            return _key_to_double(prefix.cpu().numpy().view(np.uint64))
         prefix = np.zeros((E, n_sel), dtype=np.uint64)
         rem = np.tile(np.asarray(ranks, dtype=np.int64), (E, 1))
         for shift, bits in _SELECT_DIGITS:
@@ -725,6 +737,14 @@ class SimulationController:
         if t is None or tuple(t.shape) != tuple(shape):
             bufs[name] = None
             t = bufs[name] = self.backend.empty(*shape)
+        return t
+
+    def _buffer_typed(self, name: str, dtype, numel: int):
+        bufs = self.__dict__.setdefault("_buffers", {})
+        t = bufs.get(name)
+        if t is None or t.dtype != dtype or t.numel() < numel:
+            bufs[name] = None
+            t = bufs[name] = self.backend.empty(numel, dtype=dtype)
         return t
 
     def _fused_pass(self, paths_out=None):
