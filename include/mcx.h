@@ -422,6 +422,12 @@ typedef struct {
 int  mcx_lsm_run(mcx_handle* h, mcx_book* book, int32_t product, const mcx_lsm_date* h_dates, int32_t n_dates,
                  const double* d_paths, int64_t n_paths, int64_t ld, double* d_W, int64_t ld_w,
                  double* h_coeffs, int32_t* h_status, int32_t flags, void* stream);
+/* One date of that chain for callers that own the exchange between roll and solve (several GPUs under torch.distributed: mcx_lsm_step
+ * leaves the moments on the device, the caller all-reduces them stream-ordered, mcx_lsm_solve runs the K x K solve and the
+ * coefficient scatter of `date` on the device: d_table [n_dates][n_states][K] and d_status [n_dates] as in mcx_lsm_run, entry
+ * date_index).  No host round trip per date. */
+int  mcx_lsm_solve(mcx_handle* h, mcx_book* book, int32_t product, const double* d_moments, const mcx_lsm_date* date,
+                   int32_t date_index, double* d_table, int32_t* d_status, void* stream);
 
 /* Product-batched LSM step (books of thousands of products: tests/exposure_tests/cva_perfprmance_large_netting_set.py): the
  * step of mcx_lsm_step for n_jobs products with the SAME number of exercise states in one launch.  Job j uses the cashflow

@@ -559,6 +559,22 @@ extern "C" int mcx_lsm_step(mcx_handle* h, const mcx_book* b, int32_t product, i
                            d_moments, flags, (hipStream_t)stream, "mcx_lsm_step");
 }
 
+extern "C" int mcx_lsm_solve(mcx_handle* h, mcx_book* b, int32_t product, const double* d_moments, const mcx_lsm_date* date,
+                             int32_t date_index, double* d_table, int32_t* d_status, void* stream)
+{
+    if (!h || !b || !d_moments || !date || !d_table || !d_status) return -1;
+    if (product < 0 || product >= b->n_products || date_index < 0) MCX_FAIL(h, -2, "mcx_lsm_solve: product / date index out of range");
+    const int K = b->n_basis, S = b->h_products[product].n_states;
+    for (int w = 0; w < 2; ++w)
+        if (date->coeff_off[w] >= 0 && date->coeff_off[w] + (int64_t)S * K > b->n_coeffs) MCX_FAIL(h, -2, "mcx_lsm_solve: coefficient offset out of range");
+    K3Solve sv;
+    sv.shift = date->shift; sv.scale = date->scale; sv.x0 = date->x0; sv.off0 = date->coeff_off[0]; sv.off1 = date->coeff_off[1];
+    sv.degenerate = date->degenerate; sv.K = K; sv.S = S; sv.date = date_index;
+    hipLaunchKernelGGL(k3_solve, dim3(1), dim3(64), 0, (hipStream_t)stream, d_moments, sv, b->d_coeffs, d_table, d_status);
+    MCX_HIP(h, hipGetLastError());
+    return 0;
+}
+
 extern "C" int mcx_lsm_run(mcx_handle* h, mcx_book* b, int32_t product, const mcx_lsm_date* h_dates, int32_t n_dates,
                            const double* d_paths, int64_t n_paths, int64_t ld, double* d_W, int64_t ld_w,
                            double* h_coeffs, int32_t* h_status, int32_t flags, void* stream)

@@ -22,7 +22,7 @@ _EXPORTS = [
     "mcx_sim_create", "mcx_sim_destroy", "mcx_generate_paths", "mcx_generate_paths_from_state", "mcx_rng_draws",
     "mcx_comm_unique_id", "mcx_comm_init", "mcx_comm_destroy", "mcx_allreduce_f64", "mcx_allgather_f64",
     "mcx_book_create", "mcx_book_destroy", "mcx_book_set_coeffs", "mcx_eval_book", "mcx_resolve_atoms",
-    "mcx_lsm_stats", "mcx_lsm_step", "mcx_lsm_run", "mcx_lsm_step_batch", "mcx_book_set_coeffs_batch", "mcx_book_set_bridge_rng", "mcx_book_set_exercise_replay",
+    "mcx_lsm_stats", "mcx_lsm_step", "mcx_lsm_run", "mcx_lsm_solve", "mcx_lsm_step_batch", "mcx_book_set_coeffs_batch", "mcx_book_set_bridge_rng", "mcx_book_set_exercise_replay",
     "mcx_fused_is_straight_line", "mcx_tangent_paths", "mcx_tangent_lsm", "mcx_tangent_eval", "mcx_tangent_cva", "mcx_tangent_profiles", "mcx_tangent_pick",
     "mcx_box_muller", "mcx_tangent_european", "mcx_fused_create", "mcx_fused_destroy", "mcx_fused_num_records", "mcx_fused_run", "mcx_fused_eval_paths", "mcx_fused_run_device", "mcx_fused_eval_paths_device",
     "mcx_reduce_vector", "mcx_reduce_profiles", "mcx_reduce_cva", "mcx_unsecured", "mcx_select_hist", "mcx_select_hist_dev", "mcx_select_narrow",
@@ -417,6 +417,13 @@ class HipBackend:
             C.c_int64(n), _vp(W.data_ptr()), C.c_int64(W.shape[1]), _abi.ptr(coeffs), _abi.ptr(status), C.c_int32(int(flags)),
             self._stream()), "mcx_lsm_run")
         return coeffs, status
+
+    def lsm_solve(self, book, product: int, moments: torch.Tensor, date: np.ndarray, date_index: int, table: torch.Tensor,
+                  status: torch.Tensor):
+        """K x K solve + coefficient scatter of one LSM date on the device (moments: device tensor, e.g. all-reduced over the ranks)"""
+        d = np.ascontiguousarray(date, dtype=_abi.LSM_DATE_DTYPE).reshape(1)
+        self._check(self.lib.mcx_lsm_solve(self.h, book.ptr, C.c_int32(product), _vp(moments.data_ptr()), _abi.ptr(d), C.c_int32(date_index),
+                                           _vp(table.data_ptr()), _vp(status.data_ptr()), self._stream()), "mcx_lsm_solve")
 
     def lsm_step_batch(self, book, jobs: np.ndarray, n_states: int, paths: torch.Tensor, W: torch.Tensor, ld_w: int,
                        flags: int = 0) -> np.ndarray:
