@@ -441,6 +441,22 @@ typedef struct {
 int  mcx_lsm_step_batch(mcx_handle* h, const mcx_book* book, const mcx_lsm_job* h_jobs, int32_t n_jobs, int32_t n_states,
                         const double* d_paths, int64_t n_paths, int64_t ld, double* d_W, int64_t ld_w, int64_t w_len,
                         double* h_moments, int32_t flags, void* stream);     /* w_len: doubles in d_W (bounds of w_offset) */
+/* The same step with the moments left on the device (d_moments [n_jobs][NM], stream-ordered), and the K x K solves + coefficient
+ * scatter of all its systems on the device: a big book's backward induction is then (step, [all-reduce], solve) pairs enqueued
+ * back to back — ~600 of them for the reference's 5,000-product book — instead of a host round trip with a batched numpy solve per
+ * step.  d_flag: one int32 the caller zeroes once; set to 1 if any system was numerically singular (its coefficients are not
+ * written: repeat with mcx_lsm_step_batch and a host solver).  mcx_book_get_coeffs reads coefficients back (synchronises). */
+typedef struct {
+    double  shift, scale, x0;     /* basis map z = (x - shift) * scale; x0: the common x of a degenerate (rank-1) system */
+    int64_t coeff_off[2];         /* where the [n_states][K] block goes in the book's coefficient array (-1: nowhere)     */
+    int32_t degenerate, reserved;
+} mcx_lsm_solve_job;
+int  mcx_lsm_step_batch_dev(mcx_handle* h, const mcx_book* book, const mcx_lsm_job* h_jobs, int32_t n_jobs, int32_t n_states,
+                            const double* d_paths, int64_t n_paths, int64_t ld, double* d_W, int64_t ld_w, int64_t w_len,
+                            double* d_moments, int32_t flags, void* stream);
+int  mcx_lsm_solve_batch(mcx_handle* h, mcx_book* book, const mcx_lsm_solve_job* h_jobs, int32_t n_jobs, int32_t n_states,
+                         const double* d_moments, int32_t* d_flag, void* stream);
+int  mcx_book_get_coeffs(mcx_handle* h, const mcx_book* book, int64_t offset, int64_t count, double* h_out, void* stream);
 /* coeffs[h_offsets[j] + q] = h_values[j * len + q], q < len, for n blocks in one call (the batched form of mcx_book_set_coeffs) */
 int  mcx_book_set_coeffs_batch(mcx_handle* h, mcx_book* book, const int64_t* h_offsets, int32_t n, int32_t len,
                                const double* h_values, void* stream);

@@ -373,10 +373,9 @@ struct K3Solve {
     int32_t degenerate, K, S, date;
 };
 
-__global__ void k3_solve(const double* __restrict__ m, const K3Solve q, double* __restrict__ coeffs, double* __restrict__ table,
-                         int32_t* __restrict__ status)
+__device__ void k3_solve_body(const double* __restrict__ m, const K3Solve& q, double* __restrict__ coeffs, double* __restrict__ table,
+                              int32_t* __restrict__ status)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const int K = q.K, S = q.S;
     double out[MCX_MAX_STATES][MCX_MAX_BASIS];
     for (int s = 0; s < S; ++s) for (int k = 0; k < K; ++k) out[s][k] = 0.0;
@@ -434,12 +433,19 @@ __global__ void k3_solve(const double* __restrict__ m, const K3Solve q, double* 
     for (int s = 0; s < S; ++s)
         for (int k = 0; k < K; ++k) {
             const double c = out[s][k];
-            table[((int64_t)q.date * S + s) * K + k] = c;
+            if (table) table[((int64_t)q.date * S + s) * K + k] = c;
             if (st == 0) {
                 if (q.off0 >= 0) coeffs[q.off0 + s * K + k] = c;
                 if (q.off1 >= 0) coeffs[q.off1 + s * K + k] = c;
             }
         }
+}
+
+__global__ void k3_solve(const double* __restrict__ m, const K3Solve q, double* __restrict__ coeffs, double* __restrict__ table,
+                         int32_t* __restrict__ status)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    k3_solve_body(m, q, coeffs, table, status);
 }
 
 template <int K, int S>
@@ -614,18 +620,23 @@ extern "C" int mcx_lsm_run(mcx_handle* h, mcx_book* b, int32_t product, const mc
     return rc;
 }
 
-extern "C" int mcx_lsm_step_batch(mcx_handle* h, const mcx_book* b, const mcx_lsm_job* h_jobs, int32_t n_jobs, int32_t n_states,
-                                  const double* d_paths, int64_t n_paths, int64_t ld, double* d_W, int64_t ld_w, int64_t w_len,
-                                  double* h_moments, int32_t flags, void* stream)
+// h_moments: host output (synchronises) or NULL; d_moments: device output [n_jobs][NM] (stream-ordered) or NULL
+static int lsm_step_batch_impl(mcx_handle* h, const mcx_book* b, const mcx_lsm_job* h_jobs, int32_t n_jobs, int32_t n_states,
+                               const double* d_paths, int64_t n_paths, int64_t ld, double* d_W, int64_t ld_w, int64_t w_len,
+                               double* h_moments, double* d_moments, int32_t flags, void* stream)
 {
-    if (!h || !b || !h_jobs || !d_paths || !d_W || !h_moments) return -1;
+    if (!h || !b || !h_jobs || !d_paths || !d_W || (!h_moments && !d_moments)) return -1;
     if (n_jobs <= 0) return 0;
     const int K = b->n_basis, S = n_states;
     if (S < 1 || S > MCX_MAX_STATES) MCX_FAIL(h, -2, "mcx_lsm_step_batch: n_states out of range");
     const int NM = (2 * K - 1) + S * K;
     if (ld < n_paths || ld_w < n_paths) MCX_FAIL(h, -2, "mcx_lsm_step_batch: leading dimension < n_paths");
     hipStream_t s = (hipStream_t)stream;
-    if (n_paths <= 0) { memset(h_moments, 0, sizeof(double) * (size_t)n_jobs * NM); return 0; }
+    if (n_paths <= 0) {
+        if (h_moments) memset(h_moments, 0, sizeof(double) * (size_t)n_jobs * NM);
+        if (d_moments) MCX_HIP(h, hipMemsetAsync(d_moments, 0, sizeof(double) * (size_t)n_jobs * NM, s));
+        return 0;
+    }
     auto flat = [&](int id) { DevAtom o; const mcx_atom& q = b->h_atoms[id]; o.t_idx = q.t_idx; o.col = q.col; o.a = q.a; o.d = q.d; o.b = q.b; o.c0 = q.c0; o.c1 = q.c1; return o; };
     std::vector<K3Job> jobs((size_t)n_jobs);
     for (int j = 0; j < n_jobs; ++j) {
@@ -672,12 +683,84 @@ extern "C" int mcx_lsm_step_batch(mcx_handle* h, const mcx_book* b, const mcx_ls
         default: rc = -1; break;
         }
         if (rc != 0) break;
-        hipLaunchKernelGGL(k3_finish_batch, dim3(nj), dim3(64), 0, s, d_part, NM, bpj, d_out, NM);
-        if (hipMemcpyAsync(h_moments + (size_t)j0 * NM, d_out, sizeof(double) * (size_t)nj * NM, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = -100; break; }
-        if (hipStreamSynchronize(s) != hipSuccess) { rc = -100; break; }
+        double* dst = d_moments ? d_moments + (size_t)j0 * NM : d_out;
+        hipLaunchKernelGGL(k3_finish_batch, dim3(nj), dim3(64), 0, s, d_part, NM, bpj, dst, NM);
+        if (h_moments) {
+            if (hipMemcpyAsync(h_moments + (size_t)j0 * NM, dst, sizeof(double) * (size_t)nj * NM, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = -100; break; }
+            if (hipStreamSynchronize(s) != hipSuccess) { rc = -100; break; }
+        }
     }
     if (rc == -1) MCX_FAIL(h, -3, "mcx_lsm_step_batch: unsupported (basis=%d, states=%d)", K, S);
     if (rc != 0) MCX_FAIL(h, -100, "mcx_lsm_step_batch: HIP error: %s", hipGetErrorString(hipGetLastError()));
+    return 0;
+}
+
+extern "C" int mcx_lsm_step_batch(mcx_handle* h, const mcx_book* b, const mcx_lsm_job* h_jobs, int32_t n_jobs, int32_t n_states,
+                                  const double* d_paths, int64_t n_paths, int64_t ld, double* d_W, int64_t ld_w, int64_t w_len,
+                                  double* h_moments, int32_t flags, void* stream)
+{
+    if (!h_moments) return -1;
+    return lsm_step_batch_impl(h, b, h_jobs, n_jobs, n_states, d_paths, n_paths, ld, d_W, ld_w, w_len, h_moments, nullptr, flags, stream);
+}
+
+extern "C" int mcx_lsm_step_batch_dev(mcx_handle* h, const mcx_book* b, const mcx_lsm_job* h_jobs, int32_t n_jobs, int32_t n_states,
+                                      const double* d_paths, int64_t n_paths, int64_t ld, double* d_W, int64_t ld_w, int64_t w_len,
+                                      double* d_moments, int32_t flags, void* stream)
+{
+    if (!d_moments) return -1;
+    return lsm_step_batch_impl(h, b, h_jobs, n_jobs, n_states, d_paths, n_paths, ld, d_W, ld_w, w_len, nullptr, d_moments, flags, stream);
+}
+
+namespace {
+struct K3SolveJob { double shift, scale, x0; int64_t off0, off1; int32_t degenerate, pad; };
+// one thread per (product, date) system of a batched step: solve + coefficient scatter on the device; a numerically singular
+// system raises the flag (its coefficients are not written: the caller repeats the induction with the host solver)
+__global__ __launch_bounds__(64) void k3_solve_batch(const double* __restrict__ moments, const K3SolveJob* __restrict__ jobs, int n_jobs,
+                                                     int K, int S, double* __restrict__ coeffs, int32_t* __restrict__ flag)
+{
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    if (j >= n_jobs) return;
+    const K3SolveJob q = jobs[j];
+    K3Solve sv;
+    sv.shift = q.shift; sv.scale = q.scale; sv.x0 = q.x0; sv.off0 = q.off0; sv.off1 = q.off1;
+    sv.degenerate = q.degenerate; sv.K = K; sv.S = S; sv.date = 0;
+    int32_t st = 0;
+    k3_solve_body(moments + (int64_t)j * ((2 * K - 1) + S * K), sv, coeffs, nullptr, &st);
+    if (st) atomicOr(flag, 1);
+}
+}  // namespace
+
+extern "C" int mcx_lsm_solve_batch(mcx_handle* h, mcx_book* b, const mcx_lsm_solve_job* h_jobs, int32_t n_jobs, int32_t n_states,
+                                   const double* d_moments, int32_t* d_flag, void* stream)
+{
+    if (!h || !b || !h_jobs || !d_moments || !d_flag) return -1;
+    if (n_jobs <= 0) return 0;
+    const int K = b->n_basis, S = n_states;
+    if (S < 1 || S > MCX_MAX_STATES) MCX_FAIL(h, -2, "mcx_lsm_solve_batch: n_states out of range");
+    std::vector<K3SolveJob> jobs((size_t)n_jobs);
+    for (int j = 0; j < n_jobs; ++j) {
+        const mcx_lsm_solve_job& q = h_jobs[j];
+        for (int w = 0; w < 2; ++w)
+            if (q.coeff_off[w] >= 0 && q.coeff_off[w] + (int64_t)S * K > b->n_coeffs) MCX_FAIL(h, -2, "mcx_lsm_solve_batch: job %d coefficient offset out of range", j);
+        K3SolveJob& o = jobs[j];
+        o.shift = q.shift; o.scale = q.scale; o.x0 = q.x0; o.off0 = q.coeff_off[0]; o.off1 = q.coeff_off[1]; o.degenerate = q.degenerate; o.pad = 0;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    K3SolveJob* d_jobs = (K3SolveJob*)mcx_scratch(h, 1, sizeof(K3SolveJob) * (size_t)n_jobs);      // (slot 1: the step's job table is consumed by then, stream order)
+    if (!d_jobs) return -100;
+    MCX_HIP(h, hipMemcpyAsync(d_jobs, jobs.data(), sizeof(K3SolveJob) * (size_t)n_jobs, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k3_solve_batch, dim3((n_jobs + 63) / 64), dim3(64), 0, s, d_moments, d_jobs, n_jobs, K, S, b->d_coeffs, d_flag);
+    MCX_HIP(h, hipGetLastError());
+    return 0;
+}
+
+extern "C" int mcx_book_get_coeffs(mcx_handle* h, const mcx_book* b, int64_t offset, int64_t count, double* h_out, void* stream)
+{
+    if (!h || !b || !h_out) return -1;
+    if (offset < 0 || count < 0 || offset + count > b->n_coeffs) MCX_FAIL(h, -2, "mcx_book_get_coeffs: range out of bounds");
+    if (count == 0) return 0;
+    MCX_HIP(h, hipMemcpyAsync(h_out, b->d_coeffs + offset, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    MCX_HIP(h, hipStreamSynchronize((hipStream_t)stream));
     return 0;
 }
 

@@ -93,4 +93,8 @@ LSM_JOB_DTYPE = np.dtype([("product", np.int32), ("roll_begin", np.int32), ("rol
                           ("x_atom", np.int32), ("reserved", np.int32), ("w_offset", np.int64), ("shift", np.float64),
                           ("scale", np.float64)], align=True)
 
+LSM_SOLVE_JOB_DTYPE = np.dtype([("shift", np.float64), ("scale", np.float64), ("x0", np.float64), ("coeff_off", np.int64, (2,)),
+                                ("degenerate", np.int32), ("reserved", np.int32)], align=True)
+assert LSM_SOLVE_JOB_DTYPE.itemsize == 48
+
 TANGENT_NP = 4          # MCX_TANGENT_NP: model parameters per forward-mode pass (csrc/kt_book.hip)

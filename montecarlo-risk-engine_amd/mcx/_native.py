@@ -22,7 +22,7 @@ _EXPORTS = [
     "mcx_sim_create", "mcx_sim_destroy", "mcx_generate_paths", "mcx_generate_paths_from_state", "mcx_rng_draws",
     "mcx_comm_unique_id", "mcx_comm_init", "mcx_comm_destroy", "mcx_allreduce_f64", "mcx_allgather_f64",
     "mcx_book_create", "mcx_book_destroy", "mcx_book_set_coeffs", "mcx_eval_book", "mcx_resolve_atoms",
-    "mcx_lsm_stats", "mcx_lsm_step", "mcx_lsm_run", "mcx_lsm_solve", "mcx_lsm_step_batch", "mcx_book_set_coeffs_batch", "mcx_book_set_bridge_rng", "mcx_book_set_exercise_replay",
+    "mcx_lsm_stats", "mcx_lsm_step", "mcx_lsm_run", "mcx_lsm_solve", "mcx_lsm_step_batch", "mcx_lsm_step_batch_dev", "mcx_lsm_solve_batch", "mcx_book_get_coeffs", "mcx_book_set_coeffs_batch", "mcx_book_set_bridge_rng", "mcx_book_set_exercise_replay",
     "mcx_fused_is_straight_line", "mcx_tangent_paths", "mcx_tangent_lsm", "mcx_tangent_eval", "mcx_tangent_cva", "mcx_tangent_profiles", "mcx_tangent_pick",
     "mcx_box_muller", "mcx_tangent_european", "mcx_fused_create", "mcx_fused_destroy", "mcx_fused_num_records", "mcx_fused_run", "mcx_fused_eval_paths", "mcx_fused_run_device", "mcx_fused_eval_paths_device",
     "mcx_reduce_vector", "mcx_reduce_profiles", "mcx_reduce_cva", "mcx_unsecured", "mcx_select_hist", "mcx_select_hist_dev", "mcx_select_narrow",
@@ -436,6 +436,31 @@ class HipBackend:
             self.h, book.ptr, _abi.ptr(jobs), C.c_int32(len(jobs)), C.c_int32(n_states), _vp(paths.data_ptr()), C.c_int64(n),
             C.c_int64(n), _vp(W.data_ptr()), C.c_int64(ld_w), C.c_int64(W.numel()), _abi.ptr(out), C.c_int32(int(flags)), self._stream()),
             "mcx_lsm_step_batch")
+        return out
+
+    def lsm_step_batch_dev(self, book, jobs: np.ndarray, n_states: int, paths: torch.Tensor, W: torch.Tensor, ld_w: int,
+                           flags: int = 0) -> torch.Tensor:
+        """lsm_step_batch with the moments left on the device ([n_jobs][NM] tensor, stream-ordered)"""
+        jobs = np.ascontiguousarray(jobs, dtype=_abi.LSM_JOB_DTYPE)
+        n = paths.shape[2]
+        K = book.plan.n_basis
+        out = self.empty(len(jobs), (2 * K - 1) + n_states * K)
+        self._check(self.lib.mcx_lsm_step_batch_dev(
+            self.h, book.ptr, _abi.ptr(jobs), C.c_int32(len(jobs)), C.c_int32(n_states), _vp(paths.data_ptr()), C.c_int64(n),
+            C.c_int64(n), _vp(W.data_ptr()), C.c_int64(ld_w), C.c_int64(W.numel()), _vp(out.data_ptr()), C.c_int32(int(flags)),
+            self._stream()), "mcx_lsm_step_batch_dev")
+        return out
+
+    def lsm_solve_batch(self, book, solve_jobs: np.ndarray, n_states: int, moments: torch.Tensor, flag: torch.Tensor):
+        """K x K solves + coefficient scatter of a batched step on the device; flag: int32 device tensor [1], set on a singular system"""
+        sj = np.ascontiguousarray(solve_jobs, dtype=_abi.LSM_SOLVE_JOB_DTYPE)
+        self._check(self.lib.mcx_lsm_solve_batch(self.h, book.ptr, _abi.ptr(sj), C.c_int32(len(sj)), C.c_int32(n_states),
+                                                 _vp(moments.data_ptr()), _vp(flag.data_ptr()), self._stream()), "mcx_lsm_solve_batch")
+
+    def book_get_coeffs(self, book) -> np.ndarray:
+        out = np.zeros(len(book.plan.coeffs))
+        self._check(self.lib.mcx_book_get_coeffs(self.h, book.ptr, C.c_int64(0), C.c_int64(len(out)), _abi.ptr(out), self._stream()),
+                    "mcx_book_get_coeffs")
         return out
 
     def book_set_coeffs_batch(self, book, offsets: np.ndarray, values: np.ndarray):

@@ -494,6 +494,11 @@ class SimulationController:
                             num=[a_[0] for a_ in atoms], x=[a_[1] for a_ in atoms], xmin=lo, deg=deg,
                             shift=np.where(deg, lo, 0.5 * (lo + hi)), scale=np.where(deg, 1.0, 2.0 / np.where(deg, 1.0, hi - lo))))
         max_len = max(cl["L"] for cl in cls)
+        # solves on the device when the backend has them: (step, all-reduce, solve) enqueued back to back for all ~600 steps of a
+        # big book, one read-back of the coefficient array at the end; a singular system anywhere repeats the induction with
+        # the host solver (which falls back to lstsq)
+        on_device = hasattr(be, "lsm_solve_batch") and not getattr(self, "_lsm_host_solves", False)
+        flag = be.zeros(1, dtype=torch.int32) if on_device else None
         for r in range(max_len):
             for S in sorted({cl["S"] for cl in cls if cl["L"] > r}):
                 blocks, xmin_b, deg_b, t_rows, t_offs, row0 = [], [], [], [], [], 0
@@ -514,6 +519,18 @@ class SimulationController:
                         t_rows.append(rows); t_offs.append(cl["expo_base"] + cl["expo_idx"][r] * S * K)
                     row0 += n_m
                 arr = np.concatenate(blocks)
+                if on_device:
+                    sj = np.zeros(len(arr), dtype=_abi.LSM_SOLVE_JOB_DTYPE)
+                    sj["shift"], sj["scale"], sj["x0"], sj["degenerate"] = arr["shift"], arr["scale"], np.concatenate(xmin_b), np.concatenate(deg_b)
+                    sj["coeff_off"][:] = -1
+                    filled = np.zeros(len(arr), dtype=np.int64)
+                    for rows, offs in zip(t_rows, t_offs):                    # at most two targets per system: product / exposure block
+                        sj["coeff_off"][rows, filled[rows]] = offs
+                        filled[rows] += 1
+                    mom = be.lsm_step_batch_dev(self.book, arr, S, paths, W, n_local, flags=lsm_flags)
+                    shard.all_reduce_(mom)
+                    be.lsm_solve_batch(self.book, sj, S, mom, flag)
+                    continue
                 mom = be.lsm_step_batch(self.book, arr, S, paths, W, n_local, flags=lsm_flags)
                 mom = shard.all_reduce_np(mom)
                 coeffs = solve_normal_equations_batch(mom, K, S, arr["shift"], arr["scale"], np.concatenate(deg_b),
@@ -523,6 +540,16 @@ class SimulationController:
                     vals = coeffs[rows]
                     be.book_set_coeffs_batch(self.book, offs, vals)
                     mirror[offs[:, None] + np.arange(S * K)[None, :]] = vals
+        if on_device:
+            if int(flag.cpu()[0]) != 0:
+                self._lsm_host_solves = True
+                try:
+                    be.book_reset_coeffs(self.book, self._coeffs_at_upload)
+                    return self._perform_regression_batched(shard, jobs, x_range, paths, n_local, K, lsm_flags)
+                finally:
+                    self._lsm_host_solves = False
+            mirror = be.book_get_coeffs(self.book)
+            self.book.plan.coeffs[:] = mirror                                 # (the host image of the uploaded book follows)
         E = len(self.exposure_timeline)
         for p_i, p, _, _ in jobs:
             S = p.get_num_states()
