@@ -317,6 +317,12 @@ int  mcx_fused_run(mcx_handle* h, const mcx_fused* f, uint64_t seed, uint64_t pa
 int  mcx_fused_run_device(mcx_handle* h, const mcx_fused* f, uint64_t seed, uint64_t path_offset, int64_t n_paths,
                           double* d_paths, int64_t ld, double* d_cfs, double* d_expo, int64_t ld_out,
                           const double* d_inject_z, const double* d_inject_u, mcx_acc* d_out, void* stream);
+/* Measurement: time the MAIN kernel of a fused pass alone (not the few-microsecond record merge that follows it) with event pairs
+ * recorded around its launch on the launch stream.  mcx_fused_set_timing(f, 1) arms a ring of MCX_FUSED_TIMING_RING pairs;
+ * mcx_fused_kernel_times synchronises the recorded pairs, returns their durations in launch order (ms) and re-arms the ring. */
+#define MCX_FUSED_TIMING_RING 64
+int  mcx_fused_set_timing(mcx_fused* f, int32_t enable);
+int  mcx_fused_kernel_times(mcx_fused* f, float* h_ms, int32_t capacity, int32_t* n_out);
 
 /* same event/metric program on a paths tensor produced earlier by mcx_generate_paths: ONE pass over the paths replaces
  * mcx_eval_book + mcx_reduce_* (no exposure matrix is written unless d_expo is given). Record layout as mcx_fused_run. */

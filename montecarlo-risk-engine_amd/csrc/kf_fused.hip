@@ -423,11 +423,48 @@ struct mcx_fused {
     double* d_partials;
     size_t partial_bytes;
     mcx_acc* d_out;
+    // optional timing of the main kernel alone (mcx_fused_set_timing): event pairs around its launch, on the launch stream
+    mutable hipEvent_t tev[2 * MCX_FUSED_TIMING_RING];
+    mutable int timing, t_count;
 };
+
+static void fused_timing_off(mcx_fused* f)
+{
+    if (f->timing) for (int q = 0; q < 2 * MCX_FUSED_TIMING_RING; ++q) hipEventDestroy(f->tev[q]);
+    f->timing = 0; f->t_count = 0;
+}
+
+extern "C" int mcx_fused_set_timing(mcx_fused* f, int32_t enable)
+{
+    if (!f) return -1;
+    fused_timing_off(f);
+    if (enable) {
+        for (int q = 0; q < 2 * MCX_FUSED_TIMING_RING; ++q)
+            if (hipEventCreate(&f->tev[q]) != hipSuccess) { for (int r = 0; r < q; ++r) hipEventDestroy(f->tev[r]); return -100; }
+        f->timing = 1;
+    }
+    return 0;
+}
+
+extern "C" int mcx_fused_kernel_times(mcx_fused* f, float* h_ms, int32_t capacity, int32_t* n_out)
+{
+    if (!f || !h_ms || !n_out) return -1;
+    *n_out = 0;
+    if (!f->timing) return 0;
+    const int n = f->t_count < capacity ? f->t_count : capacity;
+    for (int q = 0; q < n; ++q) {
+        if (hipEventSynchronize(f->tev[2 * q + 1]) != hipSuccess) return -100;
+        if (hipEventElapsedTime(&h_ms[q], f->tev[2 * q], f->tev[2 * q + 1]) != hipSuccess) return -100;
+    }
+    *n_out = n;
+    f->t_count = 0;
+    return 0;
+}
 
 extern "C" void mcx_fused_destroy(mcx_fused* f)
 {
     if (!f) return;
+    fused_timing_off(f);
     hipFree(f->d_lterms); hipFree(f->d_prog); hipFree(f->d_fast); hipFree(f->d_date_off); hipFree(f->d_date_row); hipFree(f->d_partials); hipFree(f->d_out);
     delete f;
 }
@@ -754,6 +791,8 @@ static int fused_run_impl(mcx_handle* h, const mcx_fused* f, bool simulate, uint
     hipStream_t s = (hipStream_t)stream;
     const bool inj = d_inject_z != nullptr;
     int grid;
+    const bool timed = f->timing && f->t_count < MCX_FUSED_TIMING_RING;
+    if (timed) MCX_HIP(h, hipEventRecord(f->tev[2 * f->t_count], s));
     if (f->lean && (simulate || !inj)) {
         // every date is a straight-line record: the two-paths-per-lane kernel of kf_lean.hip (simulating, or streaming a paths tensor)
         grid = mcx_launch_kf_lean(a, sd, h->n_cu, inj, simulate, s);
@@ -785,6 +824,7 @@ static int fused_run_impl(mcx_handle* h, const mcx_fused* f, bool simulate, uint
         }
     }
     MCX_HIP(h, hipGetLastError());
+    if (timed) { MCX_HIP(h, hipEventRecord(f->tev[2 * f->t_count + 1], s)); ++f->t_count; }
     hipLaunchKernelGGL(kf_merge, dim3(f->n_rec), dim3(MCX_BLOCK), 0, s, f->d_partials, f->n_rec, grid, d_out ? d_out : f->d_out);
     MCX_HIP(h, hipGetLastError());
     if (d_out) return 0;

@@ -24,7 +24,7 @@ _EXPORTS = [
     "mcx_book_create", "mcx_book_destroy", "mcx_book_set_coeffs", "mcx_eval_book", "mcx_resolve_atoms",
     "mcx_lsm_stats", "mcx_lsm_step", "mcx_lsm_run", "mcx_lsm_solve", "mcx_lsm_step_batch", "mcx_lsm_step_batch_dev", "mcx_lsm_solve_batch", "mcx_book_get_coeffs", "mcx_book_set_coeffs_batch", "mcx_book_set_bridge_rng", "mcx_book_set_exercise_replay",
     "mcx_fused_is_straight_line", "mcx_tangent_paths", "mcx_tangent_lsm", "mcx_tangent_eval", "mcx_tangent_cva", "mcx_tangent_profiles", "mcx_tangent_pick",
-    "mcx_box_muller", "mcx_tangent_european", "mcx_fused_create", "mcx_fused_destroy", "mcx_fused_num_records", "mcx_fused_run", "mcx_fused_eval_paths", "mcx_fused_run_device", "mcx_fused_eval_paths_device",
+    "mcx_box_muller", "mcx_tangent_european", "mcx_fused_create", "mcx_fused_destroy", "mcx_fused_num_records", "mcx_fused_run", "mcx_fused_eval_paths", "mcx_fused_run_device", "mcx_fused_eval_paths_device", "mcx_fused_set_timing", "mcx_fused_kernel_times",
     "mcx_reduce_vector", "mcx_reduce_profiles", "mcx_reduce_cva", "mcx_unsecured", "mcx_select_hist", "mcx_select_hist_dev", "mcx_select_narrow",
 ]
 
@@ -272,6 +272,17 @@ class HipBackend:
         self._check(self.lib.mcx_box_muller(self.h, _vp(words.data_ptr()), C.c_int64(n), C.c_int32(table_bits), _vp(u.data_ptr()),
                                             _vp(z.data_ptr()), self._stream()), "mcx_box_muller")
         return u, z
+
+    def fused_set_timing(self, f, enable: bool):
+        """arm / disarm the event pairs around the main kernel of a fused pass (measurement)"""
+        self._check(self.lib.mcx_fused_set_timing(f.ptr, C.c_int32(1 if enable else 0)), "mcx_fused_set_timing")
+
+    def fused_kernel_times(self, f) -> np.ndarray:
+        """durations (ms) of the main kernel of the passes launched since the last call (at most 64), in launch order"""
+        out = np.zeros(64, dtype=np.float32)
+        n = C.c_int32(0)
+        self._check(self.lib.mcx_fused_kernel_times(f.ptr, _abi.ptr(out), C.c_int32(64), C.byref(n)), "mcx_fused_kernel_times")
+        return out[:n.value].astype(np.float64)
 
     def fused_is_straight_line(self, f) -> bool:
         return bool(self.lib.mcx_fused_is_straight_line(f.ptr))
