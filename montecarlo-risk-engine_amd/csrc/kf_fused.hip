@@ -825,10 +825,14 @@ static int fused_run_impl(mcx_handle* h, const mcx_fused* f, bool simulate, uint
     }
     MCX_HIP(h, hipGetLastError());
     if (timed) { MCX_HIP(h, hipEventRecord(f->tev[2 * f->t_count + 1], s)); ++f->t_count; }
-    hipLaunchKernelGGL(kf_merge, dim3(f->n_rec), dim3(MCX_BLOCK), 0, s, f->d_partials, f->n_rec, grid, d_out ? d_out : f->d_out);
+    // host records: the merge kernel writes its few hundred bytes straight into the handle's pinned host buffer (mapped into the
+    // device address space): no copy kernel and no extra dispatch on the stream between the pass and its result
+    const bool direct = !d_out && sizeof(mcx_acc) * (size_t)f->n_rec <= h->pinned_bytes && h->d_pinned_alias;
+    mcx_acc* dst = d_out ? d_out : (direct ? (mcx_acc*)h->d_pinned_alias : f->d_out);
+    hipLaunchKernelGGL(kf_merge, dim3(f->n_rec), dim3(MCX_BLOCK), 0, s, f->d_partials, f->n_rec, grid, dst);
     MCX_HIP(h, hipGetLastError());
     if (d_out) return 0;
-    MCX_HIP(h, hipMemcpyAsync(h->h_pinned, f->d_out, sizeof(mcx_acc) * (size_t)f->n_rec, hipMemcpyDeviceToHost, s));
+    if (!direct) MCX_HIP(h, hipMemcpyAsync(h->h_pinned, f->d_out, sizeof(mcx_acc) * (size_t)f->n_rec, hipMemcpyDeviceToHost, s));
     MCX_HIP(h, hipStreamSynchronize(s));
     memcpy(h_out, h->h_pinned, sizeof(mcx_acc) * (size_t)f->n_rec);
     return 0;

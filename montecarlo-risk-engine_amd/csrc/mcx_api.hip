@@ -16,15 +16,16 @@ extern "C" int mcx_create(mcx_handle** out, int device_id)
     h->ws_bytes = 8u << 20;
     h->pinned_bytes = 1u << 20;
     h->small_bytes = 1u << 20; h->small_cursor = 0;
-    h->d_ws = nullptr; h->h_pinned = nullptr; h->d_small = nullptr; h->h_small = nullptr; h->d_acc = nullptr;
+    h->d_ws = nullptr; h->h_pinned = nullptr; h->d_small = nullptr; h->h_small = nullptr; h->d_acc = nullptr; h->d_pinned_alias = nullptr;
     for (int q = 0; q < 4; ++q) { h->scratch[q] = nullptr; h->scratch_bytes[q] = 0; }
     h->comm = nullptr; h->comm_ranks = 1; h->comm_rank = 0;
     const bool ok = hipMalloc(&h->d_ws, h->ws_bytes) == hipSuccess
-                 && hipHostMalloc(&h->h_pinned, h->pinned_bytes, hipHostMallocDefault) == hipSuccess
+                 && hipHostMalloc(&h->h_pinned, h->pinned_bytes, hipHostMallocMapped) == hipSuccess
                  && hipMalloc(&h->d_acc, h->pinned_bytes) == hipSuccess
                  && hipMalloc((void**)&h->d_small, h->small_bytes) == hipSuccess
                  && hipHostMalloc((void**)&h->h_small, h->small_bytes, hipHostMallocDefault) == hipSuccess;
     if (!ok) { mcx_destroy(h); return -5; }
+    if (hipHostGetDevicePointer(&h->d_pinned_alias, h->h_pinned, 0) != hipSuccess) h->d_pinned_alias = nullptr;
     *out = h;
     return 0;
 }

@@ -23,6 +23,7 @@ struct mcx_handle {
     double* d_ws;          // reduction workspace (partials)
     size_t ws_bytes;
     void* h_pinned;        // pinned staging for small device->host results
+    void* d_pinned_alias;  // the same buffer as the device addresses it (hipHostGetDevicePointer), nullptr if not mapped
     size_t pinned_bytes;
     hipDeviceProp_t prop;
     // small-descriptor staging ring: host arrays of a call (row tables, prefixes, atom ids) travel pinned -> device without a
