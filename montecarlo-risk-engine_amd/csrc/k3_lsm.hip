@@ -373,55 +373,86 @@ struct K3Solve {
     int32_t degenerate, K, S, date;
 };
 
-__device__ void k3_solve_body(const double* __restrict__ m, const K3Solve& q, double* __restrict__ coeffs, double* __restrict__ table,
-                              int32_t* __restrict__ status)
+// KK / SS > 0: basis size / state count known at compile time — every loop unrolls and the K x K system lives in registers (with
+// run-time bounds the local arrays sit in scratch memory: ~11 us for a 3 x 3 solve by one thread, mostly scratch latency).
+// Pivoting by conditional row swaps with static indices: after the r-loop row c holds the largest |entry| of column c, as with
+// LAPACK's single swap; the remaining rows may be ordered differently, the solution is the same up to rounding.
+template <int KK, int SS>
+__device__ __forceinline__ void k3_solve_t(const double* __restrict__ m, const K3Solve& q, double* __restrict__ coeffs, double* __restrict__ table,
+                                           int32_t* __restrict__ status)
 {
-    const int K = q.K, S = q.S;
-    double out[MCX_MAX_STATES][MCX_MAX_BASIS];
-    for (int s = 0; s < S; ++s) for (int k = 0; k < K; ++k) out[s][k] = 0.0;
+    const int K = KK ? KK : q.K, S = SS ? SS : q.S;
+    constexpr int KA = KK ? KK : MCX_MAX_BASIS, SA = SS ? SS : MCX_MAX_STATES;
+    double out[SA][KA];
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int k = 0; k < K; ++k) out[s][k] = 0.0;
     const double n = m[0];
     int st = 0;
     if (n > 0.0 && q.degenerate) {
-        double v[MCX_MAX_BASIS], vv = 0.0, xp = 1.0;
+        double v[KA], vv = 0.0, xp = 1.0;
+#pragma unroll
         for (int k = 0; k < K; ++k) { v[k] = xp; vv += xp * xp; xp *= q.x0; }
+#pragma unroll
         for (int s = 0; s < S; ++s) {
             const double mean_y = m[(2 * K - 1) + s * K] / n;
+#pragma unroll
             for (int k = 0; k < K; ++k) out[s][k] = v[k] * (mean_y / vv);
         }
     } else if (n > 0.0) {
-        double G[MCX_MAX_BASIS][MCX_MAX_BASIS], B[MCX_MAX_BASIS][MCX_MAX_STATES];
+        double G[KA][KA], B[KA][SA];
         double gmax = 0.0;
-        for (int j = 0; j < K; ++j) for (int k = 0; k < K; ++k) { G[j][k] = m[j + k]; gmax = fmax(gmax, fabs(G[j][k])); }
-        for (int k = 0; k < K; ++k) for (int s = 0; s < S; ++s) B[k][s] = m[(2 * K - 1) + s * K + k];
-        for (int c = 0; c < K; ++c) {                                  // LU, partial pivoting (as LAPACK dgesv)
-            int piv = c;
-            for (int r = c + 1; r < K; ++r) if (fabs(G[r][c]) > fabs(G[piv][c])) piv = r;
-            if (!(fabs(G[piv][c]) > 1e-14 * gmax)) { st = 1; break; }  // numerically singular: the caller re-solves on the host
-            if (piv != c) {
-                for (int k = 0; k < K; ++k) { const double t = G[c][k]; G[c][k] = G[piv][k]; G[piv][k] = t; }
-                for (int s = 0; s < S; ++s) { const double t = B[c][s]; B[c][s] = B[piv][s]; B[piv][s] = t; }
-            }
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+#pragma unroll
+            for (int k = 0; k < K; ++k) { G[j][k] = m[j + k]; gmax = fmax(gmax, fabs(G[j][k])); }
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int s = 0; s < S; ++s) B[k][s] = m[(2 * K - 1) + s * K + k];
+#pragma unroll
+        for (int c = 0; c < K; ++c) {                                  // LU, partial pivoting
+#pragma unroll
             for (int r = c + 1; r < K; ++r) {
-                const double f = G[r][c] / G[c][c];
+                const bool sw = fabs(G[r][c]) > fabs(G[c][c]);
+#pragma unroll
+                for (int k = 0; k < K; ++k) { const double x = G[c][k], y = G[r][k]; G[c][k] = sw ? y : x; G[r][k] = sw ? x : y; }
+#pragma unroll
+                for (int s = 0; s < S; ++s) { const double x = B[c][s], y = B[r][s]; B[c][s] = sw ? y : x; B[r][s] = sw ? x : y; }
+            }
+            if (!(fabs(G[c][c]) > 1e-14 * gmax)) st = 1;               // numerically singular: the caller re-solves on the host
+            const double piv = st ? 1.0 : G[c][c];
+#pragma unroll
+            for (int r = c + 1; r < K; ++r) {
+                const double f = G[r][c] / piv;
+#pragma unroll
                 for (int k = c + 1; k < K; ++k) G[r][k] -= f * G[c][k];
+#pragma unroll
                 for (int s = 0; s < S; ++s) B[r][s] -= f * B[c][s];
             }
         }
         if (st == 0) {
+#pragma unroll
             for (int c = K - 1; c >= 0; --c)
+#pragma unroll
                 for (int s = 0; s < S; ++s) {
                     double acc = B[c][s];
+#pragma unroll
                     for (int k = c + 1; k < K; ++k) acc -= G[c][k] * B[k][s];
                     B[c][s] = acc / G[c][c];
                 }
             // T[j][k] = coefficient of x^j in z^k = scale^k C(k, j) (-shift)^(k-j)
             double sp = 1.0;
+#pragma unroll
             for (int k = 0; k < K; ++k) {
                 double binom = 1.0;
+#pragma unroll
                 for (int j = 0; j <= k; ++j) {
                     double ms = 1.0;
                     for (int e = 0; e < k - j; ++e) ms *= -q.shift;
                     const double T = sp * binom * ms;
+#pragma unroll
                     for (int s = 0; s < S; ++s) out[s][j] += T * B[k][s];
                     binom = binom * (double)(k - j) / (double)(j + 1);
                 }
@@ -430,7 +461,9 @@ __device__ void k3_solve_body(const double* __restrict__ m, const K3Solve& q, do
         }
     }
     status[q.date] = st;
+#pragma unroll
     for (int s = 0; s < S; ++s)
+#pragma unroll
         for (int k = 0; k < K; ++k) {
             const double c = out[s][k];
             if (table) table[((int64_t)q.date * S + s) * K + k] = c;
@@ -439,6 +472,22 @@ __device__ void k3_solve_body(const double* __restrict__ m, const K3Solve& q, do
                 if (q.off1 >= 0) coeffs[q.off1 + s * K + k] = c;
             }
         }
+}
+
+__device__ void k3_solve_body(const double* __restrict__ m, const K3Solve& q, double* __restrict__ coeffs, double* __restrict__ table,
+                              int32_t* __restrict__ status)
+{
+    const int key = q.K * 16 + q.S;
+    switch (key) {
+    case 2 * 16 + 1: k3_solve_t<2, 1>(m, q, coeffs, table, status); break;
+    case 2 * 16 + 2: k3_solve_t<2, 2>(m, q, coeffs, table, status); break;
+    case 3 * 16 + 1: k3_solve_t<3, 1>(m, q, coeffs, table, status); break;
+    case 3 * 16 + 2: k3_solve_t<3, 2>(m, q, coeffs, table, status); break;
+    case 3 * 16 + 3: k3_solve_t<3, 3>(m, q, coeffs, table, status); break;
+    case 4 * 16 + 1: k3_solve_t<4, 1>(m, q, coeffs, table, status); break;
+    case 4 * 16 + 2: k3_solve_t<4, 2>(m, q, coeffs, table, status); break;
+    default: k3_solve_t<0, 0>(m, q, coeffs, table, status); break;
+    }
 }
 
 __global__ void k3_solve(const double* __restrict__ m, const K3Solve q, double* __restrict__ coeffs, double* __restrict__ table,
