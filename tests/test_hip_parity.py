@@ -5,11 +5,18 @@
  2. Philox: same seeds/counters on GPU and CPU oracle -> paths agree to <= 1e-11 relative (libm ulp differences only),
     metrics to <= 1e-9; plus RNG known-answer vectors.
  3. kernels against each other: MFMA vs VALU normal equations, radix select vs sort."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
 
 import cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
 pytestmark = pytest.mark.gpu
 NON_AAD = [n for n, c in cases.CASES.items() if not c[5]]
@@ -353,6 +360,32 @@ def test_large_book_product_batched_kernels_match_oracle(hip, oracle):
     assert np.allclose(out["hip"][0], out["oracle"][0], rtol=1e-9, atol=1e-12), (out["hip"][0], out["oracle"][0])
     assert np.allclose(out["hip"][1], out["oracle"][1], rtol=1e-9, atol=1e-10)
     assert np.allclose(out["hip"][2], out["oracle"][2], rtol=1e-9, atol=1e-9)
+    # the same book with the host solver behind the batched steps (the fallback a singular system takes): same coefficients as the
+    # device solves of the run above
+    dev = [c.numpy().copy() for c in sc.regression_coeffs]
+    sc._lsm_host_solves = True
+    sc._compiled_key = None
+    sc.run_simulation()
+    for a, b in zip(dev, [c.numpy() for c in sc.regression_coeffs]):
+        assert np.allclose(a, b, rtol=1e-8, atol=1e-9 * max(np.abs(b).max(), 1e-300))
+
+
+def test_fused_kernel_timing_entry_points(hip):
+    """mcx_fused_set_timing / mcx_fused_kernel_times: one duration per pass launched while armed, none when disarmed"""
+    import bench
+    sc = bench.build_controller(1 << 16, 4096, hip)
+    sc.prepare()
+    f = sc._fused
+    assert hip.fused_kernel_times(f).size == 0
+    hip.fused_set_timing(f, True)
+    for _ in range(3):
+        sc.main_pass()
+    t = hip.fused_kernel_times(f)
+    assert t.shape == (3,) and np.all(t > 0.0) and np.all(t < 50.0)
+    assert hip.fused_kernel_times(f).size == 0                      # the ring re-arms empty
+    hip.fused_set_timing(f, False)
+    sc.main_pass()
+    assert hip.fused_kernel_times(f).size == 0
 
 
 def test_forward_mode_cva_against_reference_autograd_and_bumps(hip):
