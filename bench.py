@@ -211,7 +211,8 @@ def main():
     # (mcx_fused_set_timing), so that the figure is the kernel alone and not kernel + the 5 us record merge that follows it
     lib_timing = fused and hasattr(be, "fused_set_timing")
     if lib_timing:
-        be.fused_set_timing(sc._fused, True)
+        # every 4th timed step carries the event pair (a pair costs ~8 us of stream time per step: 1.088 vs 1.079 ms measured)
+        be.fused_set_timing(sc._fused, 4 if args.steps >= 8 else 1)
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -244,8 +245,9 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     if lib_timing:
-        k1_ms = float(np.mean(be.fused_kernel_times(sc._fused)))        # (the first 64 steps when --steps is larger)
-        be.fused_set_timing(sc._fused, False)
+        tk = be.fused_kernel_times(sc._fused)
+        k1_ms = float(np.mean(tk)) if tk.size else float("nan")        # (the first 64 steps when --steps is larger)
+        be.fused_set_timing(sc._fused, 0)
     else:
         k1_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 

@@ -318,8 +318,10 @@ int  mcx_fused_run_device(mcx_handle* h, const mcx_fused* f, uint64_t seed, uint
                           double* d_paths, int64_t ld, double* d_cfs, double* d_expo, int64_t ld_out,
                           const double* d_inject_z, const double* d_inject_u, mcx_acc* d_out, void* stream);
 /* Measurement: time the MAIN kernel of a fused pass alone (not the few-microsecond record merge that follows it) with event pairs
- * recorded around its launch on the launch stream.  mcx_fused_set_timing(f, 1) arms a ring of MCX_FUSED_TIMING_RING pairs;
- * mcx_fused_kernel_times synchronises the recorded pairs, returns their durations in launch order (ms) and re-arms the ring. */
+ * recorded around its launch on the launch stream.  mcx_fused_set_timing(f, k) arms a ring of MCX_FUSED_TIMING_RING pairs and
+ * times every k-th launch (k = 1: all; a pair of event markers costs ~8 us of stream time on this stack, so a benchmark samples);
+ * k = 0 disarms.  mcx_fused_kernel_times synchronises the recorded pairs, returns their durations in launch order (ms) and
+ * re-arms the ring. */
 #define MCX_FUSED_TIMING_RING 64
 int  mcx_fused_set_timing(mcx_fused* f, int32_t enable);
 int  mcx_fused_kernel_times(mcx_fused* f, float* h_ms, int32_t capacity, int32_t* n_out);

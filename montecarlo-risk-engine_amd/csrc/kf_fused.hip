@@ -425,13 +425,13 @@ struct mcx_fused {
     mcx_acc* d_out;
     // optional timing of the main kernel alone (mcx_fused_set_timing): event pairs around its launch, on the launch stream
     mutable hipEvent_t tev[2 * MCX_FUSED_TIMING_RING];
-    mutable int timing, t_count;
+    mutable int timing, t_count, t_launch;      // timing: 0 off, k > 0: every k-th launch is timed
 };
 
 static void fused_timing_off(mcx_fused* f)
 {
     if (f->timing) for (int q = 0; q < 2 * MCX_FUSED_TIMING_RING; ++q) hipEventDestroy(f->tev[q]);
-    f->timing = 0; f->t_count = 0;
+    f->timing = 0; f->t_count = 0; f->t_launch = 0;
 }
 
 extern "C" int mcx_fused_set_timing(mcx_fused* f, int32_t enable)
@@ -441,7 +441,7 @@ extern "C" int mcx_fused_set_timing(mcx_fused* f, int32_t enable)
     if (enable) {
         for (int q = 0; q < 2 * MCX_FUSED_TIMING_RING; ++q)
             if (hipEventCreate(&f->tev[q]) != hipSuccess) { for (int r = 0; r < q; ++r) hipEventDestroy(f->tev[r]); return -100; }
-        f->timing = 1;
+        f->timing = enable > 0 ? enable : 1;
     }
     return 0;
 }
@@ -457,7 +457,7 @@ extern "C" int mcx_fused_kernel_times(mcx_fused* f, float* h_ms, int32_t capacit
         if (hipEventElapsedTime(&h_ms[q], f->tev[2 * q], f->tev[2 * q + 1]) != hipSuccess) return -100;
     }
     *n_out = n;
-    f->t_count = 0;
+    f->t_count = 0; f->t_launch = 0;
     return 0;
 }
 
@@ -791,7 +791,7 @@ static int fused_run_impl(mcx_handle* h, const mcx_fused* f, bool simulate, uint
     hipStream_t s = (hipStream_t)stream;
     const bool inj = d_inject_z != nullptr;
     int grid;
-    const bool timed = f->timing && f->t_count < MCX_FUSED_TIMING_RING;
+    const bool timed = f->timing && (f->t_launch++ % f->timing) == 0 && f->t_count < MCX_FUSED_TIMING_RING;
     if (timed) MCX_HIP(h, hipEventRecord(f->tev[2 * f->t_count], s));
     if (f->lean && (simulate || !inj)) {
         // every date is a straight-line record: the two-paths-per-lane kernel of kf_lean.hip (simulating, or streaming a paths tensor)

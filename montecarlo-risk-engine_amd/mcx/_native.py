@@ -273,9 +273,9 @@ class HipBackend:
                                             _vp(z.data_ptr()), self._stream()), "mcx_box_muller")
         return u, z
 
-    def fused_set_timing(self, f, enable: bool):
-        """arm / disarm the event pairs around the main kernel of a fused pass (measurement)"""
-        self._check(self.lib.mcx_fused_set_timing(f.ptr, C.c_int32(1 if enable else 0)), "mcx_fused_set_timing")
+    def fused_set_timing(self, f, every: int | bool):
+        """arm (time every `every`-th launch; True = all) / disarm (0 / False) the event pairs around the main kernel of a fused pass"""
+        self._check(self.lib.mcx_fused_set_timing(f.ptr, C.c_int32(int(every))), "mcx_fused_set_timing")
 
     def fused_kernel_times(self, f) -> np.ndarray:
         """durations (ms) of the main kernel of the passes launched since the last call (at most 64), in launch order"""
