@@ -33,7 +33,7 @@ HAZARDS = {0.5: 0.006402303360855854, 1.0: 0.01553038972325307, 2.0: 0.009729741
            15.0: 0.0036969930706003337, 20.0: 0.003791311459217732}
 HBM_PEAK_GBS = 8000.0                               # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 REF_CVA, REF_CVA_SE = 0.004623, 0.000012            # the reference itself on this workload at 50 k + 50 k paths
-KERNEL_SOURCES = ["kf_lean.hip", "kf_common.h", "mcx_device.h", "mcx_math.h"]      # what the dominant kernel is compiled from
+KERNEL_SOURCES = ["kf_lean.hip", "kf_common.h", "mcx_device.h", "mcx_math.h", "mcx_tables.h", "k1_paths.hip"]   # what the timed kernels are compiled from
 
 
 def build_controller(n_main, n_pre, backend):
