@@ -200,12 +200,12 @@ def main():
     # library launches on, _native.HipBackend._stream)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     fused = best == "fused"
-    # one-launch plan under a process group: two passes in flight — the record gather over RCCL, the copy to the host and the
+    # one-launch plan: two passes in flight — the record gather over RCCL (under a process group), the copy to the host and the
     # merge of pass k run while the kernel of pass k+1 computes (controller.fused_pass_begin / fused_pass_end); every pass still
-    # delivers its merged result inside the timed region.  Without a group there is no collective to hide (measured: 1.093 vs
-    # 1.092 ms per pass: the ~35 us between two main kernels are the record merge, the event markers and their dispatch gaps on
-    # the stream, not host latency), the plain pass is kept.
-    pipelined = fused and grouped and sc.pipelined_passes_available() and not os.environ.get("MCX_BENCH_NO_PIPELINE")
+    # delivers its merged result inside the timed region.  One GPU without a group: the records land in pinned host memory
+    # directly; 1.075-1.080 ms per pass against 1.082-1.087 for the pass that waits for its result before the next launch, and
+    # the same code path as N > 1.
+    pipelined = fused and sc.pipelined_passes_available() and not os.environ.get("MCX_BENCH_NO_PIPELINE")
     pending = None
     # the one-launch kernel is timed by the library itself: HIP event pairs recorded around its launch on the launch stream
     # (mcx_fused_set_timing), so that the figure is the kernel alone and not kernel + the 5 us record merge that follows it
