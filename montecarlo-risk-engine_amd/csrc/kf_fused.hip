@@ -730,6 +730,10 @@ extern "C" int mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_boo
     f->npf = max_chunk <= 1024 ? 1 : (max_chunk <= 2048 ? 2 : 0);
     f->chunk_cap = f->npf > 0 ? f->npf * 1024 : ((max_chunk + 255) & ~255);
     if (all_fast) { f->npf = -1; f->chunk_cap = 0; }      // no interpreted date at all: the straight-line instantiations
+    // the straight-line kernel skips the zero test under the CIR++ diffusion root: it needs a positive initial intensity (the
+    // reference asserts y0 > 0, cirpp.py:40; the state is floored at 1e-12 after every step); other starts run the interpreter
+    for (int q = 0; q < sd.n_slots; ++q)
+        if (sd.slots[q].kind == MCX_MODEL_CIRPP && !(sd.init_state[sd.slots[q].state_off] > 0.0)) lean = false;
     f->lean = lean ? 1 : 0;
     if ((size_t)4 * f->chunk_cap + sizeof(double) * 9 * (size_t)n_rec > 60 * 1024) {
         delete f;

@@ -332,7 +332,7 @@ __global__ __launch_bounds__(MCX_BLOCK, MCX_LEAN_WAVES) void kf_lean(const Fused
 #pragma unroll 1
                 while (st < 0 && step < n_steps) {
 #pragma unroll
-                    for (int q = 0; q < PPL; ++q) sim_substep<NSLOT, NZ, INJECT, SIG, BMB>(k, step, path[q], i[q], reg[q], tab, seed, bc, &vc);
+                    for (int q = 0; q < PPL; ++q) sim_substep<NSLOT, NZ, INJECT, SIG, BMB, true>(k, step, path[q], i[q], reg[q], tab, seed, bc, &vc);   // POS: mcx_fused_create
                     st = ldk(&k.steps[step].store_idx);
                     ++step;
                 }

@@ -181,7 +181,9 @@ __device__ __forceinline__ double degree_of_truth(double x, bool fuzzy, double e
 // model really uses stay live in SGPRs); -1 = wave-uniform run-time dispatch (generic kernels).
 // SL / KA below: `mcx_slot` / `K1Args`, or their constant-address-space views (kf_lean.hip reads the kernel arguments through
 // a region-local pointer into the kernarg segment, so that every field is a scalar load at its point of use)
-template <int KIND, int SCHEME, class SL>
+// POS: the caller guarantees a positive CIR++ state at entry (the model's y0 > 0, cirpp.py:40, and the 1e-12 floor after every step):
+// the root of the diffusion then needs no zero test
+template <int KIND, int SCHEME, bool POS = false, class SL>
 __device__ __forceinline__ void step_slot(const SL& sl, int scheme_rt, int flags, double dt, double sq,
                                           const double* __restrict__ aux, double& s0, double& s1, double zc0, double zc1, double u)
 {
@@ -221,7 +223,7 @@ __device__ __forceinline__ void step_slot(const SL& sl, int scheme_rt, int flags
     }
     case MCX_MODEL_CIRPP: {                                               // cirpp.py:188-198
         const double y = s0;
-        const double sy = mcx_sqrt_g(y);                  // = sqrt(clamp(y, 0)) of cirpp.py:194: mcx_sqrt_g returns 0 for y <= 0
+        const double sy = POS ? mcx_sqrt_gp(y) : mcx_sqrt_g(y);   // = sqrt(clamp(y, 0)) of cirpp.py:194: mcx_sqrt_g returns 0 for y <= 0
         // y - (kappa dt) y + (sigma sqrt(dt)) sqrt(y) z + kappa theta dt, accumulated into the state register (see VASICEK)
         const mcx_aux_drv dc = ldk_struct((const mcx_aux_drv*)(aux + MCX_AUX_C0));
         s1 = fma(y + ldk(aux + 0), dt, s1);
@@ -324,7 +326,7 @@ static inline int mcx_sim_signature(const mcx_sim_desc& d)
 }
 
 // compile-time recursion over the slots (the slot index must be a constant expression for the signature lookup)
-template <int NSLOT, int NZ, int SIG, int S, class KA>
+template <int NSLOT, int NZ, int SIG, int S, bool POS = false, class KA>
 __device__ __forceinline__ void step_slots(const KA& k, const mcx_step& sp, const double* __restrict__ ax,
                                            double (&reg)[2 * NSLOT], const double (&zc)[NZ], double u)
 {
@@ -332,15 +334,15 @@ __device__ __forceinline__ void step_slots(const KA& k, const mcx_step& sp, cons
         // ModelConfig only hosts sub-models with simulation_dim == 1 (model_config.py:106-107); Heston runs alone
         const double zc0 = (NSLOT == 1) ? zc[0] : zc[S < NZ ? S : 0];
         const double zc1 = (NSLOT == 1 && NZ > 1) ? zc[NZ > 1 ? 1 : 0] : 0.0;
-        step_slot<sig_kind(SIG, S), sig_scheme(SIG)>(k.slots[S], k.scheme, k.flags | k.slots[S].flags, sp.dt, sp.sqrt_dt,
+        step_slot<sig_kind(SIG, S), sig_scheme(SIG), POS>(k.slots[S], k.scheme, k.flags | k.slots[S].flags, sp.dt, sp.sqrt_dt,
                                                       ax + S * MCX_AUX, reg[2 * S], reg[2 * S + 1], zc0, zc1, u);
-        step_slots<NSLOT, NZ, SIG, S + 1>(k, sp, ax, reg, zc, u);
+        step_slots<NSLOT, NZ, SIG, S + 1, POS>(k, sp, ax, reg, zc, u);
     }
 }
 
 // one sub-step of the whole model for a lane: draws, Cholesky, per-slot maps.  reg[2s], reg[2s+1] = state of slot s.
 // seed / bc: the Philox key and the Box-Muller coefficients (SGPRs) of the calling code region (mcx_math.h "region zero")
-template <int NSLOT, int NZ, bool INJECT, int SIG, int BMB = 7, class KA>
+template <int NSLOT, int NZ, bool INJECT, int SIG, int BMB = 7, bool POS = false, class KA>
 __device__ __forceinline__ void sim_substep(const KA& k, int step, uint64_t path, int64_t i, double (&reg)[2 * NSLOT],
                                             const double* __restrict__ tab, uint64_t seed, const mcx_bm_coef& bc, const mcx_bm_vconst* vc = nullptr)
 {
@@ -375,7 +377,7 @@ __device__ __forceinline__ void sim_substep(const KA& k, int step, uint64_t path
         zc[r] = acc;
     }
     const double* __restrict__ ax = k.aux + (int64_t)step * NSLOT * MCX_AUX;
-    step_slots<NSLOT, NZ, SIG, 0>(k, sp, ax, reg, zc, u);
+    step_slots<NSLOT, NZ, SIG, 0, POS>(k, sp, ax, reg, zc, u);
 }
 
 template <int NSLOT, int NZ, bool INJECT, int SIG>
