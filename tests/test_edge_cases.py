@@ -134,3 +134,21 @@ def test_library_rejects_indices_a_kernel_would_read_out_of_bounds(hip):
     jobs["w_offset"] = 1
     with pytest.raises(RuntimeError, match="outside d_W"):
         hip.lsm_step_batch(sc.book, jobs, 1, paths, W, npre)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "unfused"])
+def test_cir_intensity_starting_at_zero(fused, hip, oracle, monkeypatch):
+    """the reference asserts y0 > 0 (cirpp.py:40), and the one-launch kernel relies on it (no zero test under the diffusion root);
+    a C-ABI caller may still hand over a zero start: mcx_fused_create then routes the book to the interpreter kernel, and every
+    plan reproduces sqrt(clamp(0, 0)) = 0 of cirpp.py:194 (same paths and CVA as the CPU oracle)"""
+    from mcx.models.cirpp import CIRPPModel
+    monkeypatch.setattr(CIRPPModel, "_initial_state", lambda self: [0.0, 0.0])
+    out = {}
+    for be in (hip, oracle):
+        sc, _ = cases.make_controller("irs_cva", be, inject=False, fused=fused and be is hip)
+        res = sc.run_simulation()
+        out[be.name] = (np.array(res.results[0][0][0]), sc.last_state["paths"].cpu().numpy() if be is hip else sc.last_state["paths"].numpy())
+    assert np.all(np.isfinite(out["hip"][1]))
+    assert np.allclose(out["hip"][1], out["oracle"][1], rtol=1e-10, atol=1e-13)
+    assert np.allclose(out["hip"][0], out["oracle"][0], rtol=1e-8, atol=1e-14), (out["hip"][0], out["oracle"][0])
