@@ -718,17 +718,18 @@ static int lsm_step_batch_impl(mcx_handle* h, const mcx_book* b, const mcx_lsm_j
     int rc = 0;
     for (int j0 = 0; j0 < n_jobs && rc == 0; j0 += chunk) {
         const int nj = n_jobs - j0 < chunk ? n_jobs - j0 : chunk;
-        if (hipMemcpyAsync(d_jobs, jobs.data() + j0, sizeof(K3Job) * (size_t)nj, hipMemcpyHostToDevice, s) != hipSuccess) { rc = -100; break; }
+        const K3Job* d_jobs_now = (const K3Job*)mcx_upload_call_data(h, jobs.data() + j0, sizeof(K3Job) * (size_t)nj, d_jobs, s);
+        if (!d_jobs_now) return -100;
         const dim3 grid(bpj, nj);
         switch (S) {
-        case 1: rc = dispatch_k3_batch<1>(K, a, d_jobs, grid, s); break;
-        case 2: rc = dispatch_k3_batch<2>(K, a, d_jobs, grid, s); break;
-        case 3: rc = dispatch_k3_batch<3>(K, a, d_jobs, grid, s); break;
-        case 4: rc = dispatch_k3_batch<4>(K, a, d_jobs, grid, s); break;
-        case 5: rc = dispatch_k3_batch<5>(K, a, d_jobs, grid, s); break;
-        case 6: rc = dispatch_k3_batch<6>(K, a, d_jobs, grid, s); break;
-        case 7: rc = dispatch_k3_batch<7>(K, a, d_jobs, grid, s); break;
-        case 8: rc = dispatch_k3_batch<8>(K, a, d_jobs, grid, s); break;
+        case 1: rc = dispatch_k3_batch<1>(K, a, d_jobs_now, grid, s); break;
+        case 2: rc = dispatch_k3_batch<2>(K, a, d_jobs_now, grid, s); break;
+        case 3: rc = dispatch_k3_batch<3>(K, a, d_jobs_now, grid, s); break;
+        case 4: rc = dispatch_k3_batch<4>(K, a, d_jobs_now, grid, s); break;
+        case 5: rc = dispatch_k3_batch<5>(K, a, d_jobs_now, grid, s); break;
+        case 6: rc = dispatch_k3_batch<6>(K, a, d_jobs_now, grid, s); break;
+        case 7: rc = dispatch_k3_batch<7>(K, a, d_jobs_now, grid, s); break;
+        case 8: rc = dispatch_k3_batch<8>(K, a, d_jobs_now, grid, s); break;
         default: rc = -1; break;
         }
         if (rc != 0) break;
@@ -797,8 +798,9 @@ extern "C" int mcx_lsm_solve_batch(mcx_handle* h, mcx_book* b, const mcx_lsm_sol
     hipStream_t s = (hipStream_t)stream;
     K3SolveJob* d_jobs = (K3SolveJob*)mcx_scratch(h, 1, sizeof(K3SolveJob) * (size_t)n_jobs);      // (slot 1: the step's job table is consumed by then, stream order)
     if (!d_jobs) return -100;
-    MCX_HIP(h, hipMemcpyAsync(d_jobs, jobs.data(), sizeof(K3SolveJob) * (size_t)n_jobs, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k3_solve_batch, dim3((n_jobs + 63) / 64), dim3(64), 0, s, d_moments, d_jobs, n_jobs, K, S, b->d_coeffs, d_flag);
+    const K3SolveJob* d_jobs_now = (const K3SolveJob*)mcx_upload_call_data(h, jobs.data(), sizeof(K3SolveJob) * (size_t)n_jobs, d_jobs, s);
+    if (!d_jobs_now) return -100;
+    hipLaunchKernelGGL(k3_solve_batch, dim3((n_jobs + 63) / 64), dim3(64), 0, s, d_moments, d_jobs_now, n_jobs, K, S, b->d_coeffs, d_flag);
     MCX_HIP(h, hipGetLastError());
     return 0;
 }

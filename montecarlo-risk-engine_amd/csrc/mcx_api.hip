@@ -15,7 +15,7 @@ extern "C" int mcx_create(mcx_handle** out, int device_id)
     h->n_cu = h->prop.multiProcessorCount;
     h->ws_bytes = 8u << 20;
     h->pinned_bytes = 1u << 20;
-    h->small_bytes = 1u << 20; h->small_cursor = 0;
+    h->small_bytes = 4u << 20; h->small_cursor = 0;
     h->d_ws = nullptr; h->h_pinned = nullptr; h->d_small = nullptr; h->h_small = nullptr; h->d_acc = nullptr; h->d_pinned_alias = nullptr;
     for (int q = 0; q < 4; ++q) { h->scratch[q] = nullptr; h->scratch_bytes[q] = 0; }
     h->comm = nullptr; h->comm_ranks = 1; h->comm_rank = 0;
@@ -278,6 +278,17 @@ void* mcx_stage_small(mcx_handle* h, const void* src, size_t bytes, hipStream_t 
     if (hipMemcpyAsync(dp, hp, bytes, hipMemcpyHostToDevice, s) != hipSuccess) { h->err = "hipMemcpyAsync failed"; return nullptr; }
     h->small_cursor += need;
     return dp;
+}
+
+const void* mcx_upload_call_data(mcx_handle* h, const void* src, size_t bytes, void* fallback, hipStream_t s)
+{
+    if (bytes <= h->small_bytes / 2) return mcx_stage_small(h, src, bytes, s);
+    // too large for the ring: a copy from pageable memory into the caller's device buffer, completed before `src` may go away
+    if (hipMemcpyAsync(fallback, src, bytes, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+        h->err = "host-to-device copy of a job table failed";
+        return nullptr;
+    }
+    return fallback;
 }
 
 int mcx_upload_unsec(mcx_handle* h, const mcx_unsecured_desc* u, DevUnsec* out, int32_t** d_tmp, hipStream_t s)

@@ -304,6 +304,9 @@ static inline double* mcx_path_scratch(mcx_handle* h, size_t n) { return (double
 // copy `bytes` of host data to device memory that stays valid for the kernels enqueued on `s` by the current API call (a ring:
 // wrapping synchronises the stream first); returns nullptr and sets the handle's error on failure
 void* mcx_stage_small(mcx_handle* h, const void* src, size_t bytes, hipStream_t s);
+// the same for tables that may exceed the ring (job tables of batched steps): through the ring when they fit, otherwise copied into
+// `fallback` (a device buffer of >= bytes) and completed before returning — `src` may be freed as soon as the call returns either way
+const void* mcx_upload_call_data(mcx_handle* h, const void* src, size_t bytes, void* fallback, hipStream_t s);
 int mcx_upload_unsec(mcx_handle* h, const mcx_unsecured_desc* u, DevUnsec* out, int32_t** d_tmp, hipStream_t s);
 int mcx_finish_acc(mcx_handle* h, const double* d_partials, int n_records, int n_blocks, double n_paths,
                    const double* d_shifts, mcx_acc* h_out, hipStream_t s);
