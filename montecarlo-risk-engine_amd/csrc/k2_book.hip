@@ -206,9 +206,19 @@ __global__ __launch_bounds__(MCX_BLOCK) void k2_eval_book_v(const K2Args a)
             const DevEvent e = ldk_struct(&a.events[e_i]);
             // flags bit 1: same numeraire atom as the previous event of the product (cashflow and exposure of one date): kept
             if (!(e.flags & 2) && (e.kind != MCX_EV_EXPO_BS || e.aux[2] > 0.0)) {
-                dev_atoms<PPL>(e.num, a.paths, D, ld, i, num, etab, ec);
+                if (e.num.a == 0.0 && e.num.d == 0.0 && e.num.b == 1.0 && e.num.col >= 0) {
+                    // a pure exponential (the money-market account exp(log B)): its reciprocal is the exponential of the negated
+                    // argument — no reciprocal sequence
 #pragma unroll
-                for (int q = 0; q < PPL; ++q) num[q] = mcx_rcp(num[q]);
+                    for (int q = 0; q < PPL; ++q) {
+                        const double x = a.paths[((int64_t)e.num.t_idx * D + e.num.col) * ld + i[q]];
+                        num[q] = mcx_exp_tab(-fma(e.num.c1, x, e.num.c0), etab, ec);
+                    }
+                } else {
+                    dev_atoms<PPL>(e.num, a.paths, D, ld, i, num, etab, ec);
+#pragma unroll
+                    for (int q = 0; q < PPL; ++q) num[q] = mcx_rcp(num[q]);
+                }
             }
             if (e.kind <= MCX_EV_EXERCISE) {
                 double common[PPL], own[PPL], glog[PPL];
