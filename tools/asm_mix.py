@@ -2,6 +2,10 @@
 """Static VALU instruction mix of the sub-step loop of the bench kernel (kf_lean<2,2,false,SIG_VAS_CIR_E,2>): compiles
 csrc/kf_lean.hip to gfx950 assembly and counts the instruction classes between the innermost loop header that contains the
 Philox multiplies and its back-branch.  Output (JSON on stdout): per PATH and sub-step (the loop body handles 2 paths per lane).
+The loop holds one rarely taken side block per path (the guarded root of a uniform that rounds to 1, mcx_device.h pair_from_words);
+the region counted ends at the first back-branch, so one of the two radius roots of the common path may fall outside it: the
+class split can be short of the executed one by up to half an rsq + two f64 instructions per path (< 1 % of the modelled time;
+the TOTAL the model uses is the measured SQ_INSTS_VALU, not this count).
    python tools/asm_mix.py"""
 import collections
 import json
