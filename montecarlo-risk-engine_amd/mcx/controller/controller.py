@@ -780,6 +780,14 @@ class SimulationController:
             t = bufs[name] = self.backend.empty(*shape)
         return t
 
+    def release_device_buffers(self):
+        """drop the device tensors this controller holds (paths, exposures, LSM cache, pipeline buffers): they go back to torch's
+        caching allocator at once instead of when the garbage collector gets to the controller (a bumped controller of 1 M paths
+        pins ~200 MB that the next one would otherwise have to hipMalloc again: ~80 ms)"""
+        self.last_state = {}
+        self.__dict__.pop("_buffers", None)
+        self.__dict__.pop("_pipe", None)
+
     def _buffer_typed(self, name: str, dtype, numel: int):
         bufs = self.__dict__.setdefault("_buffers", {})
         t = bufs.get(name)
