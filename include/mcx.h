@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MCX_ABI_VERSION 4   /* 4: mcx_unsecured_desc.n_rows, mcx_lsm_step_batch w_len (host-side bounds of every row / offset a kernel reads); 3: mcx_rng_draws, mcx_comm_* (RCCL), interpolated collateral; 2: batched LSM, tangent-book kernels, bridge RNG */
+#define MCX_ABI_VERSION 5   /* 5: mcx_book_set_exercise_replay n_rows, mcx_sim_create rejects (model, scheme) pairs without a step map; 4: mcx_unsecured_desc.n_rows, mcx_lsm_step_batch w_len (host-side bounds of every row / offset a kernel reads); 3: mcx_rng_draws, mcx_comm_* (RCCL), interpolated collateral; 2: batched LSM, tangent-book kernels, bridge RNG */
 
 #define MCX_MAX_SLOTS   8    /* sub-models in one ModelConfig                                  */
 #define MCX_MAX_Z       8    /* total simulation dimension (correlated normals per sub-step)    */
@@ -474,8 +474,9 @@ int  mcx_book_set_coeffs_batch(mcx_handle* h, mcx_book* book, const int64_t* h_o
  * in exercise state k (bit 0 in the main simulation).  The reference's tape carries no gradient through the boolean
  * `should_exercise` (bermudan_option.py:122-128), i.e. its sensitivities hold the exercise policy fixed: bump-and-revalue runs of
  * exercise products replay the base run's decisions so that no path flips its policy under the bump.  The fused kernels do not
- * record or replay (callers run the K1 / K2 / K4 plan while a mode is set).  ld >= the paths of the next call. */
-int  mcx_book_set_exercise_replay(mcx_handle* h, mcx_book* book, int32_t mode, uint8_t* d_bits, int64_t ld);
+ * record or replay (callers run the K1 / K2 / K4 plan while a mode is set).  ld >= the paths of the next call; n_rows = rows of d_bits,
+ * >= the number of events of the book (checked here: every (event, path) byte a kernel touches is inside the buffer). */
+int  mcx_book_set_exercise_replay(mcx_handle* h, mcx_book* book, int32_t mode, uint8_t* d_bits, int64_t n_rows, int64_t ld);
 
 /* RNG of the Brownian-bridge barrier events (OPTION mode 5), set before mcx_eval_book / mcx_lsm_step*: one uniform per monitored
  * interval k and barrier b from Philox4x32-10 with key = seed and counter = (global path id = path_offset + i, k,

@@ -149,6 +149,19 @@ extern "C" int mcx_sim_create(mcx_handle* h, const mcx_sim_desc* d, mcx_sim** ou
         if (d->slots[s].kind == MCX_MODEL_S2F && d->n_slots != 1) MCX_FAIL(h, -3, "mcx_sim_create: the Schwartz two-factor model runs alone");
         if (d->slots[s].state_off != so) MCX_FAIL(h, -4, "mcx_sim_create: state offsets must be packed");
         so += sd;
+        // the step maps that exist per model (the reference's simulate_time_step_* overrides; model.py:102-141 leaves the others
+        // unimplemented): the kernels read scheme-specific derived step constants, an unsupported pair would run on zeros
+        const int kind = d->slots[s].kind, sc = d->scheme;
+        bool ok;
+        switch (kind) {
+        case MCX_MODEL_HESTON: ok = sc == MCX_SCHEME_EULER || sc == MCX_SCHEME_QE; break;
+        case MCX_MODEL_CIRPP: ok = sc == MCX_SCHEME_EULER; break;
+        case MCX_MODEL_CIRPP_DET: ok = sc >= MCX_SCHEME_EULER && sc <= MCX_SCHEME_QE; break;
+        case MCX_MODEL_BS: case MCX_MODEL_VASICEK: case MCX_MODEL_HW: case MCX_MODEL_S2F:
+            ok = sc == MCX_SCHEME_EULER || sc == MCX_SCHEME_ANALYTICAL; break;
+        default: ok = false; break;
+        }
+        if (!ok) MCX_FAIL(h, -6, "mcx_sim_create: slot %d (model kind %d) has no step map for scheme %d", s, kind, sc);
     }
     if (so != d->n_state) MCX_FAIL(h, -4, "mcx_sim_create: n_state does not match the slots");
     for (int k = 0; k < d->n_steps; ++k) {

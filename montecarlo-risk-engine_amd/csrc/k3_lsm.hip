@@ -715,6 +715,7 @@ static int lsm_step_batch_impl(mcx_handle* h, const mcx_book* b, const mcx_lsm_j
     a.W = d_W; a.partials = d_part; a.n = n_paths; a.ld = ld; a.ld_w = ld_w; a.n_basis = K; a.n_state = b->n_state;
     a.f32_cache = (flags & MCX_LSM_F32_CACHE) ? 1 : 0; a.bridge = b->d_bridge;
     a.ex_mode = b->ex_mode; a.ex_bits = b->d_ex_bits; a.ex_ld = b->ex_ld; a.ev_base = 0;
+    if (a.ex_mode && a.ex_ld < n_paths) MCX_FAIL(h, -2, "mcx_lsm_step_batch: exercise replay buffer narrower than the path count");
     int rc = 0;
     for (int j0 = 0; j0 < n_jobs && rc == 0; j0 += chunk) {
         const int nj = n_jobs - j0 < chunk ? n_jobs - j0 : chunk;

@@ -244,10 +244,12 @@ extern "C" int mcx_book_set_bridge_rng(mcx_handle* h, mcx_book* b, uint64_t seed
     return 0;
 }
 
-extern "C" int mcx_book_set_exercise_replay(mcx_handle* h, mcx_book* b, int32_t mode, uint8_t* d_bits, int64_t ld)
+extern "C" int mcx_book_set_exercise_replay(mcx_handle* h, mcx_book* b, int32_t mode, uint8_t* d_bits, int64_t n_rows, int64_t ld)
 {
     if (!h || !b) return -1;
     if (mode < 0 || mode > 2 || (mode != 0 && (!d_bits || ld <= 0))) MCX_FAIL(h, -2, "mcx_book_set_exercise_replay: bad arguments");
+    if (mode != 0 && n_rows < b->n_events)
+        MCX_FAIL(h, -3, "mcx_book_set_exercise_replay: %lld rows for a book of %d events", (long long)n_rows, b->n_events);
     b->ex_mode = mode; b->d_ex_bits = mode ? d_bits : nullptr; b->ex_ld = mode ? ld : 0;
     return 0;
 }

@@ -5,7 +5,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_SLOTS = 8
 MAX_Z = 8
 MAX_STATE = 16

@@ -184,8 +184,9 @@ class HipBackend:
         if mode:
             assert bits.dtype == torch.uint8 and bits.is_cuda and bits.is_contiguous() and bits.shape[0] == len(book.plan.events)
         self._check(self.lib.mcx_book_set_exercise_replay(self.h, book.ptr, C.c_int32(mode), _vp(bits.data_ptr() if mode else 0),
-                                                          C.c_int64(bits.shape[1] if mode else 0)), "mcx_book_set_exercise_replay")
-        self._keep_replay = bits
+                                                          C.c_int64(bits.shape[0] if mode else 0), C.c_int64(bits.shape[1] if mode else 0)),
+                    "mcx_book_set_exercise_replay")
+        self._keep_replay = bits if mode else None
 
     def new_exercise_bits(self, n_events: int, n_paths: int) -> torch.Tensor:
         return torch.zeros((n_events, n_paths), dtype=torch.uint8, device=self.device)

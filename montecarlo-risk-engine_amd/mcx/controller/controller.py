@@ -105,6 +105,10 @@ class SimulationController:
         self.materialize = False     # also write paths / cashflows / exposures in the fused pass (inspection, tests)
         self.batch_lsm = True        # product-batched LSM pre-simulation (one launch per backward step of the whole book)
         self.forward_mode = True     # differentiate=True: dual-number pass where it exists, bump-and-revalue otherwise
+        # The reference compiles nothing: every run_simulation() sees the current state of its products / metrics.  Re-using the
+        # compiled descriptors and the uploaded book of the previous run is an opt-in for callers that re-run an UNCHANGED
+        # controller (bench.py, tools/run_configs.py); invalidate() drops the cache after a mutation.
+        self.reuse_compiled = False
         self._backend = backend
         for i, p in enumerate(products):
             p.product_id = i
@@ -570,9 +574,14 @@ class SimulationController:
         (mcx/aad.py run_with_bumps: the bumped runs of an exercise product keep the base run's exercise policy, as the
         reference's tape does — bermudan_option.py:122-128 puts no gradient through `should_exercise`)"""
         rp = getattr(self, "exercise_replay", None)
-        if not rp:
-            return
         be = self.backend
+        if not rp:
+            # a book cached across runs (_compile_all) must not keep the mode / buffer of an earlier replayed run
+            if getattr(self, "_replay_set", False):
+                be.book_set_exercise_replay(self.book, 0, None)
+                self._replay_set = False
+            return
+        self._replay_set = True
         if rp["mode"] == 1 and rp.get(phase) is None:
             rp[phase] = be.new_exercise_bits(len(self.book_plan.events), n_paths)
         be.book_set_exercise_replay(self.book, rp["mode"], rp[phase])
@@ -962,14 +971,20 @@ class SimulationController:
     def _compile_key(self):
         """everything the compiled descriptors depend on besides the (immutable) object graph of this controller: the model
         parameter VALUES (bumped runs change them), the smoothing flag and the backend"""
-        return (tuple(float(p.detach()) for p in self.model.get_model_params()), bool(self.model.perform_smoothing), id(self.backend))
+        return (tuple(float(p.detach()) for p in self.model.get_model_params()), bool(self.model.perform_smoothing), id(self.backend),
+                bool(self.materialize), bool(self.reference_float32_cf_cache), repr(getattr(self.regression_function, "degree", None)),
+                len(self.products), tuple(type(m).__name__ for m in self.risk_metrics.metrics))
+
+    def invalidate(self):
+        """forget the compiled descriptors / uploaded book (after mutating a product, a metric or a netting set)"""
+        self._compiled_key = None
 
     def _compile_all(self):
         """objects -> descriptors, LSM atoms registered before the plan is frozen and uploaded.  A controller that is run again
         with unchanged model parameters reuses the descriptors and the uploaded book of its previous run (the host-side
         compilation of a 120-date Bermudan swaption is ~25 ms of Python against ~35 ms of GPU work)."""
         key = self._compile_key()
-        if getattr(self, "_compiled_key", None) == key and getattr(self, "book", None) is not None:
+        if self.reuse_compiled and getattr(self, "_compiled_key", None) == key and getattr(self, "book", None) is not None:
             self.backend.book_reset_coeffs(self.book, self._coeffs_at_upload)
             return
         self._compile()

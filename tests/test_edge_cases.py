@@ -53,14 +53,24 @@ def test_ragged_path_counts_gpu_vs_oracle(n, fused, hip, oracle):
 
 
 def test_rerun_reuses_the_compiled_book_and_recompiles_after_a_parameter_change(oracle):
-    """a second run_simulation() of the same controller skips the host compilation (descriptor cache keyed on the model
-    parameter values) and reproduces the first run bit for bit; changing a parameter recompiles"""
+    """with reuse_compiled (opt-in) a second run_simulation() of the same controller skips the host compilation (descriptor cache
+    keyed on the model parameter values) and reproduces the first run bit for bit; changing a parameter, or invalidate() after a
+    product mutation, recompiles.  The default recompiles on every run like the reference (controller.py:663-709)."""
     import torch
     sc, _ = cases.make_controller("bermudan_swaption", oracle)
+    r1 = sc.run_simulation()
+    book0 = sc.book
+    sc.run_simulation()
+    assert sc.book is not book0                       # default: nothing is carried over
+    sc.reuse_compiled = True
     r1 = sc.run_simulation()
     book1 = sc.book
     r2 = sc.run_simulation()
     assert sc.book is book1
+    sc.invalidate()
+    sc.run_simulation()
+    assert sc.book is not book1
+    book1 = sc.book
     for a, b in zip(r1.results[0], r2.results[0]):
         assert np.array_equal(np.array(a), np.array(b))
     with torch.no_grad():
@@ -152,3 +162,39 @@ def test_cir_intensity_starting_at_zero(fused, hip, oracle, monkeypatch):
     assert np.all(np.isfinite(out["hip"][1]))
     assert np.allclose(out["hip"][1], out["oracle"][1], rtol=1e-10, atol=1e-13)
     assert np.allclose(out["hip"][0], out["oracle"][0], rtol=1e-8, atol=1e-14), (out["hip"][0], out["oracle"][0])
+
+
+@pytest.mark.gpu
+def test_library_rejects_scheme_without_step_map_and_short_replay_buffers(hip):
+    """C-ABI callers bypass the Python guards (Model._supports_scheme): mcx_sim_create refuses a (model, scheme) pair that has no
+    step map (the kernels would run on all-zero derived step constants), mcx_book_set_exercise_replay refuses a decision buffer
+    with fewer rows than the book has events, and the LSM / book kernels refuse one narrower than the path count"""
+    import torch
+    sc, _ = cases.make_controller("irs_cva", hip, inject=False)
+    sc.prepare()
+    desc = sc.sim_plan.desc
+    saved = desc.scheme
+    try:
+        for bad in (1, 3, 2):                          # MILSTEIN, QE, ANALYTICAL for Vasicek + CIR++
+            desc.scheme = bad
+            with pytest.raises(RuntimeError, match="no step map"):
+                hip.sim_create(sc.sim_plan)
+    finally:
+        desc.scheme = saved
+    hip.sim_create(sc.sim_plan)
+    sb, _ = cases.make_controller("bermudan_swaption", hip, inject=False)
+    sb.prepare()
+    n_ev = len(sb.book_plan.events)
+    bits = torch.zeros((n_ev - 1, 256), dtype=torch.uint8, device=hip.device)
+    with pytest.raises(RuntimeError, match="rows for a book"):
+        import ctypes as C
+        hip._check(hip.lib.mcx_book_set_exercise_replay(hip.h, sb.book.ptr, C.c_int32(1), C.c_void_p(bits.data_ptr()),
+                                                        C.c_int64(n_ev - 1), C.c_int64(256)), "mcx_book_set_exercise_replay")
+    narrow = torch.zeros((n_ev, 8), dtype=torch.uint8, device=hip.device)
+    hip.book_set_exercise_replay(sb.book, 1, narrow)
+    try:
+        paths = torch.zeros(sb.sim_plan.n_dates, sb.sim_plan.n_state, 1024, dtype=torch.float64, device=hip.device)
+        with pytest.raises(RuntimeError, match="narrower than the path count"):
+            hip.eval_book(sb.book, paths)
+    finally:
+        hip.book_set_exercise_replay(sb.book, 0, None)
