@@ -16,6 +16,7 @@ extern "C" int mcx_create(mcx_handle** out, int device_id)
     h->ws_bytes = 8u << 20;
     h->pinned_bytes = 1u << 20;
     h->small_bytes = 4u << 20; h->small_cursor = 0;
+    h->small_stream = nullptr; h->small_stream_valid = false;
     h->d_ws = nullptr; h->h_pinned = nullptr; h->d_small = nullptr; h->h_small = nullptr; h->d_acc = nullptr; h->d_pinned_alias = nullptr;
     for (int q = 0; q < 4; ++q) { h->scratch[q] = nullptr; h->scratch_bytes[q] = 0; }
     h->comm = nullptr; h->comm_ranks = 1; h->comm_rank = 0;
@@ -269,10 +270,20 @@ void* mcx_scratch(mcx_handle* h, int slot, size_t bytes)
 void* mcx_stage_small(mcx_handle* h, const void* src, size_t bytes, hipStream_t s)
 {
     const size_t need = (bytes + 255) & ~(size_t)255;
-    if (need > h->small_bytes) { h->err = "descriptor too large for the staging ring"; return nullptr; }
-    if (h->small_cursor + need > h->small_bytes) {                  // wrap: everything staged so far must have been consumed
+    const size_t half = h->small_bytes / 2;
+    if (need > half) { h->err = "descriptor too large for the staging ring"; return nullptr; }
+    // one stream at a time: work staged for another stream is drained before this stream's data may displace it
+    if (h->small_stream_valid && h->small_stream != s && hipStreamSynchronize(h->small_stream) != hipSuccess) {
+        h->err = "hipStreamSynchronize failed"; return nullptr;
+    }
+    h->small_stream = s; h->small_stream_valid = true;
+    const int cur = h->small_cursor >= half ? 1 : 0;
+    if (h->small_cursor + need > (size_t)(cur + 1) * half) {
+        // this half is full: drain the stream (every kernel that reads the OTHER half has then finished) and move there.  What the
+        // current call staged in this half for kernels it has not launched yet stays intact: it is displaced only after another
+        // half-ring (2 MiB) of descriptors
         if (hipStreamSynchronize(s) != hipSuccess) { h->err = "hipStreamSynchronize failed"; return nullptr; }
-        h->small_cursor = 0;
+        h->small_cursor = (size_t)(cur ^ 1) * half;
     }
     unsigned char* hp = h->h_small + h->small_cursor;
     unsigned char* dp = h->d_small + h->small_cursor;
@@ -284,7 +295,7 @@ void* mcx_stage_small(mcx_handle* h, const void* src, size_t bytes, hipStream_t 
 
 const void* mcx_upload_call_data(mcx_handle* h, const void* src, size_t bytes, void* fallback, hipStream_t s)
 {
-    if (bytes <= h->small_bytes / 2) return mcx_stage_small(h, src, bytes, s);
+    if (bytes <= h->small_bytes / 4) return mcx_stage_small(h, src, bytes, s);
     // too large for the ring: a copy from pageable memory into the caller's device buffer, completed before `src` may go away
     if (hipMemcpyAsync(fallback, src, bytes, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
         h->err = "host-to-device copy of a job table failed";

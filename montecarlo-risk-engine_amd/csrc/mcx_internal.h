@@ -31,6 +31,10 @@ struct mcx_handle {
     unsigned char* d_small;
     unsigned char* h_small;
     size_t small_bytes, small_cursor;
+    // the ring is used as two halves: moving into the other half drains the stream first, so what an API call staged stays
+    // valid until another half-ring of descriptors has been staged after it (also for kernels the call has not launched yet)
+    hipStream_t small_stream;      // the stream of the last staging call (a change of stream drains the previous one)
+    bool small_stream_valid;
     void* d_acc;           // device image of the accumulator records of a reduction call (pinned_bytes large)
     void* scratch[4];      // device scratch buffers of the entry points, grown on demand and freed with the handle
     size_t scratch_bytes[4];
