@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MCX_ABI_VERSION 5   /* 5: mcx_book_set_exercise_replay n_rows, mcx_sim_create rejects (model, scheme) pairs without a step map; 4: mcx_unsecured_desc.n_rows, mcx_lsm_step_batch w_len (host-side bounds of every row / offset a kernel reads); 3: mcx_rng_draws, mcx_comm_* (RCCL), interpolated collateral; 2: batched LSM, tangent-book kernels, bridge RNG */
+#define MCX_ABI_VERSION 5   /* 5: value polynomials (mcx_book_collapse_values), mcx_book_set_exercise_replay n_rows, mcx_sim_create rejects (model, scheme) pairs without a step map; 4: mcx_unsecured_desc.n_rows, mcx_lsm_step_batch w_len (host-side bounds of every row / offset a kernel reads); 3: mcx_rng_draws, mcx_comm_* (RCCL), interpolated collateral; 2: batched LSM, tangent-book kernels, bridge RNG */
 
 #define MCX_MAX_SLOTS   8    /* sub-models in one ModelConfig                                  */
 #define MCX_MAX_Z       8    /* total simulation dimension (correlated normals per sub-step)    */
@@ -295,6 +295,29 @@ void mcx_book_destroy(mcx_book* book);
 int  mcx_book_set_coeffs(mcx_handle* h, mcx_book* book, int64_t offset, int64_t count, const double* h_coeffs, void* stream);
 int  mcx_eval_book(mcx_handle* h, const mcx_book* book, const double* d_paths, int64_t n_paths, int64_t ld,
                    double* d_cfs, double* d_expo, int64_t ld_out, void* stream);
+/* Value polynomials.  An event whose cash value sums >= min_terms atoms of ONE state variable x of one date — a Bermudan swaption's
+ * exercise value is the underlying swap priced from ~35-64 zero-bond requests per exercise date (products/bermudan_option.py:40-43,
+ * 93-131; products/bond.py:42-68, 115-163) — is a smooth function f(x) = sum_j w_j (a_j + d_j x + b_j exp(c0_j + c1_j x)).
+ * mcx_book_collapse_values fits one polynomial per such event on [lo - pad w, hi + pad w], w = hi - lo, from the column ranges
+ * h_lo / h_hi [n_dates][n_state] (e.g. the extremes of the pre-simulation paths) and VERIFIES on the host
+ *     |p(x) - f(x)| <= rel_tol * sum_j |w_j| (|a_j| + |d_j x| + |b_j| exp(c0_j + c1_j x))
+ * on a dense grid (f in long double, p with the kernels' FMA chain).  The LSM roll (mcx_lsm_*), the book kernel and the one-launch
+ * kernel (a mcx_fused created AFTERWARDS) then evaluate ~20 multiply-adds instead of ~15 instructions per term; events whose fit
+ * misses the bound keep the term loop, and so does every wave that holds a path outside the verified range.  h_lo == NULL removes
+ * the polynomials; pad > -1/2 (a negative pad verifies a range NARROWER than the data: tests of the fallback).  Synchronises the
+ * stream.  mcx_value_poly_fit is the fit alone (host only, no GPU): coef[0..*degree] ascending in
+ * t = (x - mid) / half, *degree = -1 when no polynomial of degree <= max_degree (<= MCX_VPOLY_MAX_DEGREE) meets rel_tol. */
+#define MCX_VPOLY_MAX_DEGREE 31
+typedef struct { double w, a, d, b, c0, c1; } mcx_value_term;
+int  mcx_value_poly_fit(const mcx_value_term* terms, int32_t n_terms, double lo, double hi, double rel_tol, int32_t max_degree,
+                        double* coef, int32_t* degree, double* mid, double* half, double* max_rel_err);
+int  mcx_book_collapse_values(mcx_handle* h, mcx_book* book, const double* h_lo, const double* h_hi, int32_t n_dates, int32_t n_state,
+                              double pad, double rel_tol, int32_t min_terms, int32_t* n_collapsed, void* stream);
+/* h_out[2 q] = min, h_out[2 q + 1] = max of row q of the [n_rows][ld] tensor d_x over its first n entries (the state columns of the
+ * pre-simulation paths [n_dates * n_state][ld]: the ranges mcx_book_collapse_values wants).  Synchronises the stream. */
+int  mcx_rows_minmax(mcx_handle* h, const double* d_x, int32_t n_rows, int64_t n, int64_t ld, double* h_out, void* stream);
+/* 1 when `event` has a polynomial (its block count of 4 coefficients and verified range are returned), 0 when not, < 0 on error */
+int  mcx_book_value_poly_info(const mcx_book* book, int32_t event, int32_t* n_blocks, double* lo, double* hi);
 /* materialise resolved requests for pluggable Metric subclasses (request_interface.py:115-130): d_out [n_ids][ld_out] */
 int  mcx_resolve_atoms(mcx_handle* h, const mcx_book* book, const int32_t* h_atom_ids, int32_t n_ids,
                        const double* d_paths, int64_t n_paths, int64_t ld, double* d_out, int64_t ld_out, void* stream);

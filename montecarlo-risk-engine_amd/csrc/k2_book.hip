@@ -32,6 +32,8 @@ struct K2Args {
     uint8_t* __restrict__ ex_bits;              // exercise-decision record / replay (mcx_book_set_exercise_replay)
     int64_t ex_ld;
     int32_t ex_mode;
+    const DevVPoly* __restrict__ vpoly;         // value polynomials of the book's events (DevEvent::pad, mcx_vpoly.hip) or nullptr
+    const double* __restrict__ vcoef;
 };
 
 __device__ __forceinline__ double dev_poly(const double* __restrict__ c, int K, double x)
@@ -47,7 +49,8 @@ __device__ __forceinline__ double dev_norm_cdf(double x) { return 0.5 * (1.0 + e
 __device__ __forceinline__ double dev_cash_event(const DevEvent& e, const DevTerm* __restrict__ terms, const DevAtom* __restrict__ atoms,
                                                  const double* __restrict__ coeffs, int K, const double* __restrict__ paths,
                                                  int64_t D, int64_t ld, int64_t i, int& s, const DevBridge* __restrict__ bridge,
-                                                 int ex_mode = 0, uint8_t* __restrict__ ex_cell = nullptr)
+                                                 int ex_mode = 0, uint8_t* __restrict__ ex_cell = nullptr,
+                                                 const DevVPoly* __restrict__ vpoly = nullptr, const double* __restrict__ vcoef = nullptr)
 {
     const double num = dev_atom(e.num, paths, D, ld, i);
     double common = 0.0, own = 0.0, glog = 0.0;
@@ -65,7 +68,13 @@ __device__ __forceinline__ double dev_cash_event(const DevEvent& e, const DevTer
     }
     const bool basket = e.kind == MCX_EV_OPTION && e.aux[0] != 0.0;       // geometric aggregate needed (basket_option.py:56-82)
     AtomCache ac = {-1, -1, 0.0};
-    for (int j = e.term_begin; j < e.term_end; ++j) {
+    int j_begin = e.term_begin;
+    if (e.pad > 0 && vpoly) {                                 // the event's value as one verified polynomial (mcx_vpoly.hip)
+        const DevVPoly vp = ldk_struct(&vpoly[e.pad - 1]);
+        const double xv = paths[((int64_t)vp.t_idx * D + vp.col) * ld + i];
+        if (__all(xv >= vp.lo && xv <= vp.hi)) { common = dev_vpoly(vp, vcoef, xv); j_begin = e.term_end; }
+    }
+    for (int j = j_begin; j < e.term_end; ++j) {
         const DevTerm tm = ldk_struct(&terms[j]);
         const double av = dev_atom_cached(tm.atom, paths, D, ld, i, ac);
         const double v = tm.w * av;
@@ -123,7 +132,7 @@ __global__ __launch_bounds__(MCX_BLOCK) void k2_eval_book(const K2Args a)
             const DevEvent e = ldk_struct(&a.events[q]);
             if (e.kind <= MCX_EV_EXERCISE) {
                 acc += dev_cash_event(e, a.terms, a.atoms, a.coeffs, K, a.paths, D, ld, i, s, a.bridge, a.ex_mode,
-                                      a.ex_mode ? a.ex_bits + (int64_t)q * a.ex_ld + i : nullptr);
+                                      a.ex_mode ? a.ex_bits + (int64_t)q * a.ex_ld + i : nullptr, a.vpoly, a.vcoef);
             } else {
                 double v = 0.0;
                 if (e.kind == MCX_EV_EXPO_POLY) {
@@ -226,7 +235,23 @@ __global__ __launch_bounds__(MCX_BLOCK) void k2_eval_book_v(const K2Args a)
                 for (int q = 0; q < PPL; ++q) { common[q] = 0.0; own[q] = 0.0; glog[q] = 0.0; }
                 const bool binary = (FEAT & K2F_EXOTIC) && e.kind == MCX_EV_OPTION && e.aux[0] == 3.0;
                 const bool basket = (FEAT & K2F_EXOTIC) && e.kind == MCX_EV_OPTION && e.aux[0] != 0.0 && !binary;
-                for (int j = e.term_begin; j < e.term_end; ++j) {
+                int j_begin = e.term_begin;
+                if (e.pad > 0 && a.vpoly) {                 // the event's value as one verified polynomial (mcx_vpoly.hip)
+                    const DevVPoly vp = ldk_struct(&a.vpoly[e.pad - 1]);
+                    double xv[PPL];
+                    bool in = true;
+#pragma unroll
+                    for (int q = 0; q < PPL; ++q) {
+                        xv[q] = a.paths[((int64_t)vp.t_idx * D + vp.col) * ld + i[q]];
+                        in = in && xv[q] >= vp.lo && xv[q] <= vp.hi;
+                    }
+                    if (__all(in)) {
+#pragma unroll
+                        for (int q = 0; q < PPL; ++q) common[q] = dev_vpoly(vp, a.vcoef, xv[q]);
+                        j_begin = e.term_end;
+                    }
+                }
+                for (int j = j_begin; j < e.term_end; ++j) {
                     const DevTerm tm = ldk_struct(&a.terms[j]);
                     double av[PPL];
                     dev_atoms<PPL>(tm.atom, a.paths, D, ld, i, av, etab, ec);
@@ -387,6 +412,7 @@ extern "C" int mcx_eval_book(mcx_handle* h, const mcx_book* b, const double* d_p
     a.want_cfs = b->want_cfs; a.want_expo = b->want_expo;
     a.chunk_products = 0; a.n_netting_sets = b->n_netting_sets; a.bridge = b->d_bridge;
     a.ex_mode = b->ex_mode; a.ex_bits = b->d_ex_bits; a.ex_ld = b->ex_ld;
+    a.vpoly = b->d_vpoly; a.vcoef = b->d_vcoef;
     if (a.ex_mode && a.ex_ld < n_paths) MCX_FAIL(h, -2, "mcx_eval_book: exercise replay buffer narrower than the path count");
     const int grid = (int)((n_paths + MCX_BLOCK - 1) / MCX_BLOCK);
     // Few paths x many products (the reference's 5,000-product books run on ~1,000 paths): the path grid alone leaves the

@@ -58,6 +58,11 @@ struct FastDate {
     double ex_k0, ex_k1, ex_strike, ex_sign, ex_x_a, ex_x_d;
     // flag 512: the date's cash value is a plain option payoff (european_option.py:45-68): max(op_sign (value - op_strike), 0)
     double op_strike, op_sign;
+    // flag 1024: the exercise value (affine part, constants and every exponential term) is also available as ONE verified polynomial of
+    // reg[ex_p_reg] (mcx_vpoly.hip): p(t), t = fma(x, ex_p_ih, ex_p_ms), ex_p_blk blocks of 4 coefficients at vcoef + ex_p_off, valid
+    // for ex_p_lo <= x <= ex_p_hi; a wave that holds a path outside runs the LeanTerm loop
+    double ex_p_lo, ex_p_hi, ex_p_ms, ex_p_ih;
+    int32_t ex_p_off, ex_p_blk, ex_p_reg, ex_p_pad;
 };
 struct LeanTerm { double w, c0, c1; int32_t reg, pad; };     // w exp(c0 + c1 reg[reg]), read through scalar loads
 
@@ -65,6 +70,7 @@ struct FusedArgs {
     K1Args k1;
     const FastDate* __restrict__ fast;        // [n_dates]
     const LeanTerm* __restrict__ lterms;      // exponential terms of the exercise values (FastDate::ex_term_off)
+    const double* __restrict__ vcoef;         // coefficients of the exercise-value polynomials (FastDate::ex_p_off), one spare block at the end
     const unsigned char* __restrict__ prog;   // per-date program chunks (header | events | terms | metric ops)
     const int32_t* __restrict__ date_off;     // [n_dates+1] byte offset of each date's chunk (16-byte aligned)
     const int32_t* __restrict__ date_row;     // [n_dates] exposure row of this timeline date or -1

@@ -417,6 +417,7 @@ struct mcx_fused {
     int chunk_cap, npf;
     int lean;                  // every date has a FastDate record kf_lean.hip can run (valid != 0)
     LeanTerm* d_lterms;
+    double* d_vcoef;           // this object's copy of the exercise-value polynomial coefficients (the book may rebuild its own)
     int32_t rec_pv[MCX_FUSED_MAX_NS], rec_cva[MCX_FUSED_MAX_NS];
     double lgd[MCX_FUSED_MAX_NS];
     int32_t init_state[MCX_FUSED_MAX_STATEFUL];
@@ -465,7 +466,7 @@ extern "C" void mcx_fused_destroy(mcx_fused* f)
 {
     if (!f) return;
     fused_timing_off(f);
-    hipFree(f->d_lterms); hipFree(f->d_prog); hipFree(f->d_fast); hipFree(f->d_date_off); hipFree(f->d_date_row); hipFree(f->d_partials); hipFree(f->d_out);
+    hipFree(f->d_lterms); hipFree(f->d_vcoef); hipFree(f->d_prog); hipFree(f->d_fast); hipFree(f->d_date_off); hipFree(f->d_date_row); hipFree(f->d_partials); hipFree(f->d_out);
     delete f;
 }
 
@@ -505,6 +506,7 @@ extern "C" int mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_boo
 
     // events bucketed by timeline date, product order preserved
     std::vector<std::vector<FEvent>> by_date(T);
+    std::vector<std::vector<int>> by_date_q(T);              // book index of each bucketed event
     std::vector<std::vector<FTerm>> terms_by_date(T);
     int n_stateful = 0;
     int32_t init_state[MCX_FUSED_MAX_STATEFUL] = {0, 0, 0, 0};
@@ -542,6 +544,7 @@ extern "C" int mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_boo
             if (!by_date[t].empty() && memcmp(&by_date[t].back().num, &fe.num, sizeof(FAtom)) == 0) fe.flags |= 2;
             else fe.flags &= ~2;
             by_date[t].push_back(fe);
+            by_date_q[t].push_back(q);
         }
     }
     // metric ops
@@ -589,6 +592,7 @@ extern "C" int mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_boo
     // straight-line records for dates of the linear-book shape (FastDate); such dates need no interpreted chunk
     std::vector<FastDate> fast(T);
     std::vector<LeanTerm> lterms;
+    std::vector<double> vcoef;
     const bool fast_dates_enabled = d->n_netting_sets == 1;
     for (int t = 0; t < T; ++t) {
         FastDate fd;
@@ -599,7 +603,8 @@ extern "C" int mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_boo
         bool okf = fast_dates_enabled, lean_only = false;
         const FAtom* num = nullptr;
         int n_expo = 0;
-        for (const FEvent& e : by_date[t]) {
+        for (size_t ei = 0; ei < by_date[t].size(); ++ei) {
+            const FEvent& e = by_date[t][ei];
             if (!okf) break;
             const bool stateful = e.sidx >= 0;
             if (stateful && (e.sidx != 0 || e.pad != 2 || d->n_netting_sets != 1)) { okf = false; break; }      // one two-state product
@@ -633,6 +638,15 @@ extern "C" int mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_boo
                     }
                 }
                 fd.ex_n = (int32_t)lterms.size() - fd.ex_term_off;
+                // the book's verified value polynomial of this event (mcx_book_collapse_values), copied into this object
+                const int vq = book->h_event_vpoly.empty() ? -1 : book->h_event_vpoly[by_date_q[t][ei]];
+                if (okf && vq >= 0) {
+                    const DevVPoly& vp = book->h_vpoly[vq];
+                    fd.flags |= 1024;
+                    fd.ex_p_lo = vp.lo; fd.ex_p_hi = vp.hi; fd.ex_p_ms = vp.ms; fd.ex_p_ih = vp.ih;
+                    fd.ex_p_off = (int32_t)vcoef.size(); fd.ex_p_blk = vp.n_blk; fd.ex_p_reg = col_reg[vp.col];
+                    vcoef.insert(vcoef.end(), book->h_vcoef.begin() + vp.coef_off, book->h_vcoef.begin() + vp.coef_off + (size_t)vp.n_blk * MCX_VPOLY_BLK);
+                }
                 continue;
             }
             if (e.kind == MCX_EV_CASHFLOW || plain_option) {
@@ -750,10 +764,12 @@ extern "C" int mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_boo
     };
     prog.resize(prog.size() + 4096, 0);       // slack so the fixed-size prefetch of the last chunk stays in bounds
     lterms.resize(lterms.size() + 1);          // never empty
+    vcoef.resize(vcoef.size() + MCX_VPOLY_BLK, 0.0);      // the spare block the kernels prefetch
     f->partial_bytes = sizeof(double) * 4 * (size_t)n_rec * 2048;
     hipError_t e = up((void**)&f->d_prog, prog.data(), prog.size());
     if (e == hipSuccess) e = up((void**)&f->d_fast, fast.data(), sizeof(FastDate) * fast.size());
     if (e == hipSuccess) e = up((void**)&f->d_lterms, lterms.data(), sizeof(LeanTerm) * lterms.size());
+    if (e == hipSuccess) e = up((void**)&f->d_vcoef, vcoef.data(), sizeof(double) * vcoef.size());
     if (e == hipSuccess) e = up((void**)&f->d_date_off, date_off.data(), sizeof(int32_t) * date_off.size());
     if (e == hipSuccess) e = up((void**)&f->d_date_row, date_row.data(), sizeof(int32_t) * date_row.size());
     if (e == hipSuccess) e = hipMalloc(&f->d_partials, f->partial_bytes);
@@ -786,7 +802,7 @@ static int fused_run_impl(mcx_handle* h, const mcx_fused* f, bool simulate, uint
     FusedArgs a;
     memset(&a, 0, sizeof(a));
     mcx_fill_k1_args(f->sim, seed, path_offset, n_paths, ld > 0 ? ld : n_paths, d_paths, d_inject_z, d_inject_u, &a.k1);
-    a.prog = f->d_prog; a.fast = f->d_fast; a.lterms = f->d_lterms; a.date_off = f->d_date_off; a.chunk_cap = f->chunk_cap;
+    a.prog = f->d_prog; a.fast = f->d_fast; a.lterms = f->d_lterms; a.vcoef = f->d_vcoef; a.date_off = f->d_date_off; a.chunk_cap = f->chunk_cap;
     a.date_row = f->d_date_row; a.coeffs = f->book->d_coeffs; a.cfs = d_cfs; a.expo = d_expo; a.partials = f->d_partials;
     a.ld_out = ld_out; a.n_dates = f->n_dates; a.n_basis = f->book->n_basis; a.n_ns = f->n_ns; a.n_rec = f->n_rec;
     a.n_expo_rows = f->n_expo_rows; a.n_stateful = f->n_stateful;

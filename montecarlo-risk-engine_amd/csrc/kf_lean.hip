@@ -20,6 +20,7 @@
 //     a "region zero" (mcx_math.h), i.e. as scalar loads at the point of use.  Left alone, the backend loads all ~100
 //     argument dwords in the prologue, keeps them live through every loop and spills them to VGPR lanes; each reload is a
 //     v_readlane — a VALU instruction, the pipe this kernel is bound by (the round-1 kernel carried 82 such spills).
+#include <cstdlib>
 #include <map>
 #include <utility>
 
@@ -146,20 +147,52 @@ __device__ __forceinline__ void lean_date(int t, const int64_t (&i)[PPL], const 
         // exercise event of the two-state product (bermudan_option.py:93-131): exercise iff the immediate value exceeds the
         // regression continuation value and a right is left; the (up to ~64) exponential terms of the immediate value come
         // through scalar loads, one 32-byte record per term, and serve both paths of the lane
-        const double k0 = FD(ex_k0), k1 = FD(ex_k1), strike = FD(ex_strike), sign = FD(ex_sign);
-        const int lr = FD(ex_lin_reg), n_t = FD(ex_n);
-        const LeanTerm* __restrict__ lt = a.lterms + FD(ex_term_off);
+        const double strike = FD(ex_strike), sign = FD(ex_sign);
         double val[PPL];
+        // the whole value as ONE verified polynomial of the state variable (mcx_vpoly.hip: ~20 multiply-adds for both paths of the
+        // lane instead of ~15 VALU per term and path); a wave that holds a path outside the verified range runs the terms
+        bool collapsed = false;
+        if (flags & 1024) {
+            const double lo = FD(ex_p_lo), hi = FD(ex_p_hi);
+            const int pr = FD(ex_p_reg);
+            bool in = true;
 #pragma unroll
-        for (int q = 0; q < PPL; ++q) val[q] = fma(k1, reg[q][lr], k0);
-        // the next term's record is in flight while this term's two exponentials run (the table has one spare entry at its end)
-        LeanTerm tm = ldk_struct(lt);
+            for (int q = 0; q < PPL; ++q) in = in && reg[q][pr] >= lo && reg[q][pr] <= hi;
+            if (__all(in)) {
+                const double ms = FD(ex_p_ms), ih = FD(ex_p_ih);
+                const int nb = FD(ex_p_blk);
+                const VPolyBlk* __restrict__ blk = (const VPolyBlk*)(a.vcoef + FD(ex_p_off));
+                double tt[PPL];
+#pragma unroll
+                for (int q = 0; q < PPL; ++q) { tt[q] = fma(reg[q][pr], ih, ms); val[q] = 0.0; }
+                VPolyBlk c = ldk_struct(blk);
 #pragma unroll 1
-        for (int j = 0; j < n_t; ++j) {
-            const LeanTerm nx = ldk_struct(lt + j + 1);
+                for (int kb = 0; kb < nb; ++kb) {
+                    const VPolyBlk nx = ldk_struct(blk + kb + 1);
 #pragma unroll
-            for (int q = 0; q < PPL; ++q) val[q] = fma(tm.w, mcx_exp_tab(fma(tm.c1, reg[q][tm.reg], tm.c0), etab, ec), val[q]);
-            tm = nx;
+                    for (int j = 0; j < MCX_VPOLY_BLK; ++j)
+#pragma unroll
+                        for (int q = 0; q < PPL; ++q) val[q] = fma(val[q], tt[q], c.c[j]);
+                    c = nx;
+                }
+                collapsed = true;
+            }
+        }
+        if (!collapsed) {
+            const double k0 = FD(ex_k0), k1 = FD(ex_k1);
+            const int lr = FD(ex_lin_reg), n_t = FD(ex_n);
+            const LeanTerm* __restrict__ lt = a.lterms + FD(ex_term_off);
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) val[q] = fma(k1, reg[q][lr], k0);
+            // the next term's record is in flight while this term's two exponentials run (the table has one spare entry at its end)
+            LeanTerm tm = ldk_struct(lt);
+#pragma unroll 1
+            for (int j = 0; j < n_t; ++j) {
+                const LeanTerm nx = ldk_struct(lt + j + 1);
+#pragma unroll
+                for (int q = 0; q < PPL; ++q) val[q] = fma(tm.w, mcx_exp_tab(fma(tm.c1, reg[q][tm.reg], tm.c0), etab, ec), val[q]);
+                tm = nx;
+            }
         }
         const double xa = FD(ex_x_a), xd = FD(ex_x_d);
         const int xr = FD(ex_x_reg), co = FD(ex_coeff_off);
@@ -258,15 +291,17 @@ __device__ __forceinline__ void lean_date(int t, const int64_t (&i)[PPL], const 
     }
 }
 
-#ifndef MCX_LEAN_PPL          // (tools/build_variants.sh builds A/B variants of this file; the product uses the defaults)
-#define MCX_LEAN_PPL 2
 #define MCX_LEAN_WAVES 4
-#endif
+#define MCX_LEAN_RU 4          // sub-steps drawn ahead by the small-path-count shape (launch_lean)
 // SIMULATE = false: the same date programs on a paths tensor produced earlier by K1 (k1.paths is then the INPUT
 // [date][state][path]): one streaming pass, the next date's state columns in flight while this date's program runs
-template <int NSLOT, int NZ, bool INJECT, int SIG, int PPL, bool SIMULATE>
+// RU > 1 (small path counts, launch_lean): the draws of RU consecutive sub-steps are made TOGETHER — they depend on the counter
+// (path, step) only, so a lane that holds one path still offers RU independent Philox / Box-Muller chains to the VALU pipe;
+// the sub-steps then consume them one by one (ring of RU x NZ normals per path, indexed by a wave-uniform position)
+template <int NSLOT, int NZ, bool INJECT, int SIG, int PPL, bool SIMULATE, int RU = 1>
 __global__ __launch_bounds__(MCX_BLOCK, MCX_LEAN_WAVES) void kf_lean(const FusedArgs)      // read through kargs_region(), never by name
 {
+    static_assert(RU == 1 || (SIMULATE && !INJECT), "drawing ahead needs the counter-based generator");
     constexpr int NREG = 2 * NSLOT;
     constexpr int TILE = MCX_BLOCK * PPL;
     extern __shared__ double lds[];
@@ -317,6 +352,9 @@ __global__ __launch_bounds__(MCX_BLOCK, MCX_LEAN_WAVES) void kf_lean(const Fused
         // ONE date call site: the dates that hold the initial state come first (their sub-step run is empty), then
         // alternately a run of sub-steps up to the next timeline date and that date's program
         int step = 0, t_init = 0;
+        constexpr bool QE_U = sig_scheme(SIG) == MCX_SCHEME_QE || sig_scheme(SIG) < 0;        // the step may consume a uniform
+        double zr[PPL][RU > 1 ? RU * NZ : 1], ur[PPL][RU > 1 && QE_U ? RU : 1];               // draws made ahead (RU > 1)
+        int pos = RU;                                                                         // next unread ring entry; RU: empty
 #pragma unroll 1
         while (true) {
             const bool init = t_init < n_init;
@@ -324,15 +362,40 @@ __global__ __launch_bounds__(MCX_BLOCK, MCX_LEAN_WAVES) void kf_lean(const Fused
             int st = init ? t_init : -1;
             t_init += init ? 1 : 0;
             {
-                const int zr = mcx_region_zero();       // arguments, Philox key schedule, Box-Muller coefficients of this run
-                const auto& k = kargs_region(zr).k1;
+                const int zr0 = mcx_region_zero();      // arguments, Philox key schedule, Box-Muller coefficients of this run
+                const auto& k = kargs_region(zr0).k1;
                 const uint64_t seed = k.seed;
-                const mcx_bm_coef bc = mcx_bm_coef_load(zr);
+                const mcx_bm_coef bc = mcx_bm_coef_load(zr0);
                 const mcx_bm_vconst vc = mcx_bm_vconst_make<BMB>(bc);  // constants kept in registers across the run of sub-steps
 #pragma unroll 1
                 while (st < 0 && step < n_steps) {
+                    if constexpr (RU == 1) {
 #pragma unroll
-                    for (int q = 0; q < PPL; ++q) sim_substep<NSLOT, NZ, INJECT, SIG, BMB, true>(k, step, path[q], i[q], reg[q], tab, seed, bc, &vc);   // POS: mcx_fused_create
+                        for (int q = 0; q < PPL; ++q) sim_substep<NSLOT, NZ, INJECT, SIG, BMB, true>(k, step, path[q], i[q], reg[q], tab, seed, bc, &vc);   // POS: mcx_fused_create
+                    } else {
+                        if (pos == RU) {
+                            // refill: the draws of sub-steps step .. step + RU - 1 (counters beyond the last sub-step are drawn and dropped)
+#pragma unroll
+                            for (int r = 0; r < RU; ++r)
+#pragma unroll
+                                for (int q = 0; q < PPL; ++q) {
+                                    double zz[NZ], uu;
+                                    sim_draw<NZ, false, SIG, BMB>(k, step + r, path[q], i[q], zz, uu, tab, seed, bc, &vc);
+#pragma unroll
+                                    for (int j = 0; j < NZ; ++j) zr[q][r * NZ + j] = zz[j];
+                                    if (QE_U) ur[q][r] = uu;
+                                }
+                            pos = 0;
+                        }
+#pragma unroll
+                        for (int q = 0; q < PPL; ++q) {
+                            double zz[NZ];
+#pragma unroll
+                            for (int j = 0; j < NZ; ++j) zz[j] = zr[q][pos * NZ + j];          // wave-uniform index: M0-relative register read
+                            sim_apply<NSLOT, NZ, SIG, true>(k, step, reg[q], zz, QE_U ? ur[q][pos] : 0.0);
+                        }
+                        ++pos;
+                    }
                     st = ldk(&k.steps[step].store_idx);
                     ++step;
                 }
@@ -393,15 +456,10 @@ __global__ __launch_bounds__(MCX_BLOCK, MCX_LEAN_WAVES) void kf_lean(const Fused
 
 #undef FD
 
-template <int NSLOT, int NZ, int SIG>
-void launch_lean(const FusedArgs& a, int n_cu, bool inject, bool simulate, hipStream_t s, int* grid_out)
+// launch of one (paths per lane, draws made ahead) shape of the kernel; returns the grid
+template <int NSLOT, int NZ, int SIG, int PPL, int RU>
+int launch_lean_shape(const FusedArgs& a, int n_cu, bool inject, bool simulate, hipStream_t s)
 {
-    // two paths per lane where both fit the 128-VGPR budget of 4 waves per SIMD; the generic (run-time model dispatch) kernels of
-    // several sub-models carry every model's step code and would spill (3 slots: 1.2 KB of scratch per lane): one path per lane
-#ifndef MCX_LEAN_PPL_HESTON
-#define MCX_LEAN_PPL_HESTON MCX_LEAN_PPL
-#endif
-    constexpr int PPL = (SIG == SIG_GENERIC && NSLOT >= 2) ? 1 : (SIG == SIG_HESTON_QE ? MCX_LEAN_PPL_HESTON : MCX_LEAN_PPL);
     const int64_t tiles = (a.k1.n + MCX_BLOCK * PPL - 1) / (MCX_BLOCK * PPL);
     const size_t lds = sizeof(double) * (size_t)((9 * a.n_rec + 1) & ~1);
     // blocks that are really co-resident: __launch_bounds__(256, 4) guarantees the registers of 4 blocks per CU, but a book with
@@ -424,7 +482,11 @@ void launch_lean(const FusedArgs& a, int n_cu, bool inject, bool simulate, hipSt
         return (int)((tiles + per - 1) / per);
     };
     int grid;
-    if (!simulate) {
+    if constexpr (RU > 1) {
+        auto kern = kf_lean<NSLOT, NZ, false, SIG, PPL, true, RU>;
+        grid = sized(residency(kern));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(MCX_BLOCK), lds, s, a);
+    } else if (!simulate) {
         auto kern = kf_lean<NSLOT, NZ, false, SIG, PPL, false>;
         grid = sized(residency(kern));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(MCX_BLOCK), lds, s, a);
@@ -437,7 +499,44 @@ void launch_lean(const FusedArgs& a, int n_cu, bool inject, bool simulate, hipSt
         grid = sized(residency(kern));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(MCX_BLOCK), lds, s, a);
     }
-    *grid_out = grid;
+    return grid;
+}
+
+template <int NSLOT, int NZ, int SIG>
+void launch_lean(const FusedArgs& a, int n_cu, bool inject, bool simulate, hipStream_t s, int* grid_out)
+{
+    // Full shape: two paths per lane where both fit the 128-VGPR budget of 4 waves per SIMD (the generic run-time-dispatch kernels
+    // of several sub-models carry every model's step code and would spill: one path per lane).  512 paths per block-tile, 4 blocks
+    // per CU: 2^19 paths fill the chip once.
+    constexpr int PPL = (SIG == SIG_GENERIC && NSLOT >= 2) ? 1 : 2;
+#ifdef MCX_LEAN_AB
+    // tools/build_variants.sh only: every candidate shape, picked by the environment (never defined in the product build)
+    if (simulate && !inject) {
+        const char* sh = getenv("MCX_LEAN_SHAPE");
+        const int code = sh ? atoi(sh) : 0;               // 10 * PPL + RU
+        switch (code) {
+        case 12: *grid_out = launch_lean_shape<NSLOT, NZ, SIG, 1, 2>(a, n_cu, inject, simulate, s); return;
+        case 13: *grid_out = launch_lean_shape<NSLOT, NZ, SIG, 1, 3>(a, n_cu, inject, simulate, s); return;
+        case 14: *grid_out = launch_lean_shape<NSLOT, NZ, SIG, 1, 4>(a, n_cu, inject, simulate, s); return;
+        case 15: *grid_out = launch_lean_shape<NSLOT, NZ, SIG, 1, 5>(a, n_cu, inject, simulate, s); return;
+        case 11: *grid_out = launch_lean_shape<NSLOT, NZ, SIG, 1, 1>(a, n_cu, inject, simulate, s); return;
+        case 22: *grid_out = launch_lean_shape<NSLOT, NZ, SIG, 2, 2>(a, n_cu, inject, simulate, s); return;
+        case 24: *grid_out = launch_lean_shape<NSLOT, NZ, SIG, 2, 4>(a, n_cu, inject, simulate, s); return;
+        case 21: *grid_out = launch_lean_shape<NSLOT, NZ, SIG, 2, 1>(a, n_cu, inject, simulate, s); return;
+        default: break;
+        }
+    }
+#endif
+    // Small path counts (one GPU's share of a strong-scaled run: 2^20 paths over 8 GPUs = 2^17 each): the full shape would leave
+    // one wave per SIMD on a kernel that needs ~8 independent instruction streams per SIMD to keep the VALU pipe issuing.  One path
+    // per lane doubles the waves; drawing MCX_LEAN_RU sub-steps ahead gives each of them that many independent RNG chains.
+    constexpr int RU = MCX_LEAN_RU;
+    const int64_t full_tiles = (a.k1.n + MCX_BLOCK * PPL - 1) / (MCX_BLOCK * PPL);
+    if (PPL == 2 && simulate && !inject && full_tiles <= (int64_t)2 * n_cu) {
+        *grid_out = launch_lean_shape<NSLOT, NZ, SIG, 1, RU>(a, n_cu, inject, simulate, s);
+        return;
+    }
+    *grid_out = launch_lean_shape<NSLOT, NZ, SIG, PPL, 1>(a, n_cu, inject, simulate, s);
 }
 
 }  // namespace

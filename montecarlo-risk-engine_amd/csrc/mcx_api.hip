@@ -183,6 +183,8 @@ extern "C" int mcx_book_create(mcx_handle* h, const mcx_book_desc* d, mcx_book**
     b->d_atoms = nullptr; b->d_terms = nullptr; b->d_events = nullptr; b->d_products = nullptr; b->d_coeffs = nullptr;
     b->d_bridge = nullptr; b->d_bridge_inject = nullptr;
     b->ex_mode = 0; b->d_ex_bits = nullptr; b->ex_ld = 0;
+    b->d_vpoly = nullptr; b->d_vcoef = nullptr;
+    b->h_event_vpoly.assign((size_t)d->n_events, -1);
     auto upload = [&](void** dst, const void* src, size_t bytes) -> bool {        // false: the error is in h->err; the caller frees
         hipError_t e = hipMalloc(dst, bytes ? bytes : 8);
         if (e == hipSuccess && src && bytes) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
@@ -207,6 +209,7 @@ extern "C" void mcx_book_destroy(mcx_book* b)
     if (!b) return;
     hipFree(b->d_atoms); hipFree(b->d_terms); hipFree(b->d_events); hipFree(b->d_products); hipFree(b->d_coeffs);
     hipFree(b->d_bridge); hipFree(b->d_bridge_inject);
+    hipFree(b->d_vpoly); hipFree(b->d_vcoef);
     delete b;
 }
 

@@ -340,14 +340,14 @@ __device__ __forceinline__ void step_slots(const KA& k, const mcx_step& sp, cons
     }
 }
 
-// one sub-step of the whole model for a lane: draws, Cholesky, per-slot maps.  reg[2s], reg[2s+1] = state of slot s.
+// the draws of one sub-step of a lane's path: NZ standard normals (+ the uniform of the Heston QE step).  They depend on the counter
+// (path, step) only, never on the state: a kernel may draw several sub-steps ahead (kf_lean.hip, small path counts)
 // seed / bc: the Philox key and the Box-Muller coefficients (SGPRs) of the calling code region (mcx_math.h "region zero")
-template <int NSLOT, int NZ, bool INJECT, int SIG, int BMB = 7, bool POS = false, class KA>
-__device__ __forceinline__ void sim_substep(const KA& k, int step, uint64_t path, int64_t i, double (&reg)[2 * NSLOT],
-                                            const double* __restrict__ tab, uint64_t seed, const mcx_bm_coef& bc, const mcx_bm_vconst* vc = nullptr)
+template <int NZ, bool INJECT, int SIG, int BMB = 7, class KA>
+__device__ __forceinline__ void sim_draw(const KA& k, int step, uint64_t path, int64_t i, double (&z)[NZ], double& u,
+                                         const double* __restrict__ tab, uint64_t seed, const mcx_bm_coef& bc, const mcx_bm_vconst* vc = nullptr)
 {
-    const mcx_step sp = ldk_struct(&k.steps[step]);    // wave-uniform -> scalar loads
-    double z[NZ], zc[NZ], u = 0.0;
+    u = 0.0;
     if (INJECT) {
 #pragma unroll
         for (int j = 0; j < NZ; ++j) z[j] = k.inject_z[((int64_t)step * NZ + j) * k.ld + i];
@@ -366,6 +366,14 @@ __device__ __forceinline__ void sim_substep(const KA& k, int step, uint64_t path
             draw_pair<false>(seed, path, (uint32_t)step, (uint32_t)((NZ + 1) / 2), u, z0, z1, nullptr, bc);
         }
     }
+}
+
+// the state update of one sub-step from its draws: Cholesky, per-slot maps.  reg[2s], reg[2s+1] = state of slot s.
+template <int NSLOT, int NZ, int SIG, bool POS = false, class KA>
+__device__ __forceinline__ void sim_apply(const KA& k, int step, double (&reg)[2 * NSLOT], const double (&z)[NZ], double u)
+{
+    const mcx_step sp = ldk_struct(&k.steps[step]);    // wave-uniform -> scalar loads
+    double zc[NZ];
     const double* __restrict__ L = k.chol + (int64_t)sp.chol_idx * NZ * NZ;     // model.py:48  z @ chol.T
     // EULER / QE correlate with the factor of a CORRELATION matrix (model.py:66-73): its first entry is sqrt(1) = 1 exactly
     constexpr bool UNIT_L00 = sig_scheme(SIG) == MCX_SCHEME_EULER || sig_scheme(SIG) == MCX_SCHEME_QE;
@@ -378,6 +386,16 @@ __device__ __forceinline__ void sim_substep(const KA& k, int step, uint64_t path
     }
     const double* __restrict__ ax = k.aux + (int64_t)step * NSLOT * MCX_AUX;
     step_slots<NSLOT, NZ, SIG, 0, POS>(k, sp, ax, reg, zc, u);
+}
+
+// one sub-step of the whole model for a lane: draws, Cholesky, per-slot maps
+template <int NSLOT, int NZ, bool INJECT, int SIG, int BMB = 7, bool POS = false, class KA>
+__device__ __forceinline__ void sim_substep(const KA& k, int step, uint64_t path, int64_t i, double (&reg)[2 * NSLOT],
+                                            const double* __restrict__ tab, uint64_t seed, const mcx_bm_coef& bc, const mcx_bm_vconst* vc = nullptr)
+{
+    double z[NZ], u;
+    sim_draw<NZ, INJECT, SIG, BMB>(k, step, path, i, z, u, tab, seed, bc, vc);
+    sim_apply<NSLOT, NZ, SIG, POS>(k, step, reg, z, u);
 }
 
 template <int NSLOT, int NZ, bool INJECT, int SIG>

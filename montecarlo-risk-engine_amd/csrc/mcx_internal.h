@@ -73,12 +73,21 @@ struct DevEvent {
     int32_t kind, flags;    // flags bit0: exposure row is accumulated (+=) instead of stored
     int32_t term_begin, term_end;
     int32_t coeff_off, row;
-    int32_t netting_set, pad;
+    int32_t netting_set, pad;       // pad: 1 + index of the event's value polynomial (DevVPoly), 0 = none
     double strike, sign;
     double aux[4];
     DevAtom num;
     DevAtom x;
 };
+
+// value polynomial of an event (mcx_vpoly.hip): sum of the event's terms = p(t), t = fma(x, ih, ms), x = paths[t_idx][col], valid
+// for lo <= x <= hi; n_blk blocks of MCX_VPOLY_BLK coefficients at coef_off, highest power first (zero-padded in front)
+#define MCX_VPOLY_BLK 4
+struct DevVPoly {
+    double lo, hi, ms, ih;
+    int32_t coef_off, n_blk, t_idx, col;
+};
+struct VPolyBlk { double c[MCX_VPOLY_BLK]; };
 
 struct DevProduct {
     int32_t ev_begin, ev_end, cf_begin, cf_end;
@@ -105,6 +114,13 @@ struct mcx_book {
     int ex_mode;
     uint8_t* d_ex_bits;
     int64_t ex_ld;
+    // value polynomials (mcx_book_collapse_values)
+    DevVPoly* d_vpoly;
+    double* d_vcoef;
+    std::vector<DevVPoly> h_vpoly;
+    std::vector<double> h_vcoef;
+    std::vector<int32_t> h_event_vpoly;   // [n_events] index into h_vpoly or -1
+    std::vector<double> vpoly_key;        // (tolerance, candidate events and ranges) of the last mcx_book_collapse_values
     std::vector<uint8_t> ns_has_writer;   // [n_netting_sets * n_expo_rows]
     bool expo_needs_memset;
 };
@@ -212,6 +228,23 @@ __device__ __forceinline__ double dev_atom_cached_tab(const DevAtom& a, const do
     return v;
 }
 
+
+// value polynomial of an event at x (mcx_vpoly.hip): wave-uniform record and coefficients -> scalar loads, the next block of
+// coefficients in flight while the current one is consumed (the pool ends with one spare block).  Caller: x inside [vp.lo, vp.hi].
+__device__ __forceinline__ double dev_vpoly(const DevVPoly& vp, const double* __restrict__ vcoef, double x)
+{
+    const double t = fma(x, vp.ih, vp.ms);
+    const VPolyBlk* __restrict__ blk = (const VPolyBlk*)(vcoef + vp.coef_off);
+    VPolyBlk c = ldk_struct(blk);
+    double p = 0.0;
+    for (int k = 0; k < vp.n_blk; ++k) {
+        const VPolyBlk nx = ldk_struct(blk + k + 1);
+#pragma unroll
+        for (int j = 0; j < MCX_VPOLY_BLK; ++j) p = fma(p, t, c.c[j]);
+        c = nx;
+    }
+    return p;
+}
 
 // exercise decision with optional record / replay (mcx_book_set_exercise_replay): `cell` = the (event, path) byte, `bit` = the
 // hypothetical start state of the LSM roll (0 in the main simulation)

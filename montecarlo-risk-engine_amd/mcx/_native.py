@@ -25,6 +25,7 @@ _EXPORTS = [
     "mcx_lsm_stats", "mcx_lsm_step", "mcx_lsm_run", "mcx_lsm_solve", "mcx_lsm_step_batch", "mcx_lsm_step_batch_dev", "mcx_lsm_solve_batch", "mcx_book_get_coeffs", "mcx_book_set_coeffs_batch", "mcx_book_set_bridge_rng", "mcx_book_set_exercise_replay",
     "mcx_fused_is_straight_line", "mcx_tangent_paths", "mcx_tangent_lsm", "mcx_tangent_eval", "mcx_tangent_cva", "mcx_tangent_profiles", "mcx_tangent_pick",
     "mcx_box_muller", "mcx_tangent_european", "mcx_fused_create", "mcx_fused_destroy", "mcx_fused_num_records", "mcx_fused_run", "mcx_fused_eval_paths", "mcx_fused_run_device", "mcx_fused_eval_paths_device", "mcx_fused_set_timing", "mcx_fused_kernel_times",
+    "mcx_value_poly_fit", "mcx_book_collapse_values", "mcx_book_value_poly_info", "mcx_rows_minmax",
     "mcx_reduce_vector", "mcx_reduce_profiles", "mcx_reduce_cva", "mcx_unsecured", "mcx_select_hist", "mcx_select_hist_dev", "mcx_select_narrow",
 ]
 
@@ -396,6 +397,31 @@ class HipBackend:
         return out
 
     # ---- K3 ------------------------------------------------------------------------------------------------------
+    def rows_minmax(self, x: torch.Tensor) -> np.ndarray:
+        """[rows][2] (min, max) of every row of a 2-D view of `x` (last dimension = paths)"""
+        n = x.shape[-1]
+        rows = x.numel() // n
+        assert x.is_contiguous()
+        out = np.zeros((rows, 2))
+        self._check(self.lib.mcx_rows_minmax(self.h, _vp(x.data_ptr()), C.c_int32(rows), C.c_int64(n), C.c_int64(n), _abi.ptr(out), self._stream()),
+                    "mcx_rows_minmax")
+        return out
+
+    def book_collapse_values(self, book, lo, hi, pad: float = 0.3, rel_tol: float = 1e-14, min_terms: int = 6) -> int:
+        """fit + verify the value polynomials of the book's many-term events on the column ranges lo / hi [n_dates][n_state]
+        (mcx_book_collapse_values); None removes them.  Returns the number of collapsed events."""
+        n = C.c_int32(0)
+        if lo is None:
+            self._check(self.lib.mcx_book_collapse_values(self.h, book.ptr, None, None, C.c_int32(0), C.c_int32(0), C.c_double(0.0), C.c_double(1.0),
+                                                          C.c_int32(2), C.byref(n), self._stream()), "mcx_book_collapse_values")
+            return 0
+        lo = np.ascontiguousarray(lo, dtype=np.float64); hi = np.ascontiguousarray(hi, dtype=np.float64)
+        assert lo.shape == hi.shape and lo.ndim == 2
+        self._check(self.lib.mcx_book_collapse_values(self.h, book.ptr, _abi.ptr(lo), _abi.ptr(hi), C.c_int32(lo.shape[0]), C.c_int32(lo.shape[1]),
+                                                      C.c_double(pad), C.c_double(rel_tol), C.c_int32(min_terms), C.byref(n), self._stream()),
+                    "mcx_book_collapse_values")
+        return int(n.value)
+
     def lsm_stats(self, book, atom_ids, paths: torch.Tensor) -> np.ndarray:
         ids = np.ascontiguousarray(atom_ids, dtype=np.int32)
         n = paths.shape[2]

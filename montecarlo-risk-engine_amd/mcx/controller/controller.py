@@ -109,6 +109,10 @@ class SimulationController:
         # compiled descriptors and the uploaded book of the previous run is an opt-in for callers that re-run an UNCHANGED
         # controller (bench.py, tools/run_configs.py); invalidate() drops the cache after a mutation.
         self.reuse_compiled = False
+        # value polynomials (mcx_vpoly.hip): on by default, exact term loops when off
+        self.collapse_values = True
+        self.collapse_pad, self.collapse_rel_tol, self.collapse_min_terms = 0.3, 1e-14, 6
+        self.n_collapsed_events = 0
         self._backend = backend
         for i, p in enumerate(products):
             p.product_id = i
@@ -379,6 +383,7 @@ class SimulationController:
             eng.inject_z, eng.inject_u = self._inject["pre"]
         paths = eng.generate_paths_native()
         self.last_state["paths_pre"] = paths
+        self._collapse_values(shard, paths)
         self._set_bridge_rng(eng.seed, off, "bridge_pre")
         self._set_exercise_replay("pre", n_local)
         K = self.regression_function.get_degree()
@@ -424,6 +429,24 @@ class SimulationController:
                 if expo_idx is not None:
                     self.regression_coeffs[p_i][expo_idx] = torch.from_numpy(coeffs)
                     be.book_set_coeffs(self.book, self._expo_coeff_base[p_i] + expo_idx * S * K, coeffs)
+
+    def _collapse_values(self, shard: Shard, paths):
+        """events that sum many atoms of one state variable (a Bermudan swaption's exercise value: the underlying swap priced
+        from ~35-64 zero-bond requests per date, bermudan_option.py:40-43) become one host-verified polynomial of that variable
+        on the range the pre-simulation paths visit, padded by 30 % on either side (mcx_book_collapse_values); the LSM roll and
+        the main pass evaluate ~20 multiply-adds per path and date instead of ~15 instructions per term, paths outside the
+        verified range take the exact term loop.  All ranks use the same (gathered) ranges: results do not depend on the sharding."""
+        be = self.backend
+        if not self.collapse_values or not hasattr(be, "book_collapse_values"):
+            return
+        ev = self.book_plan.events
+        if len(ev) == 0 or int((ev["term_end"] - ev["term_begin"]).max()) < self.collapse_min_terms:
+            return
+        mm = be.rows_minmax(paths)                                     # [T * D][2]
+        g = shard.all_gather_np(mm)
+        T, D = paths.shape[0], paths.shape[1]
+        lo, hi = g[:, :, 0].min(axis=0).reshape(T, D), g[:, :, 1].max(axis=0).reshape(T, D)
+        self.n_collapsed_events = be.book_collapse_values(self.book, lo, hi, self.collapse_pad, self.collapse_rel_tol, self.collapse_min_terms)
 
     def _lsm_on_device(self, be, p_i, p, sched, atoms, x_range, paths, W, S, K, lsm_flags, shard=None) -> bool:
         """the product's whole backward induction enqueued on the device (mcx_lsm_run): roll, moments, K x K solve and coefficient
