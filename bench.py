@@ -9,6 +9,10 @@ CVA reduction (+ the collective).  The LSM pre-simulation (131,072 paths per GPU
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--paths P] [--scaling weak|strong]
 
+`value` is the figure of --scaling (default weak: P paths PER GPU, the per-GPU work is fixed as N grows).  The metric is quoted on
+1 M paths IN TOTAL, so the same line also carries `strong`: the same K steps timed on 1,048,576 paths split over the N GPUs
+(131,072 per GPU at N = 8), and `sustained`: a second timed region of >= 1 s of passes (K steps of 1 ms are 20 ms of work).
+
 --gpus N > 1 without a torch.distributed environment: this process starts N ranks itself
 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>`) BEFORE
 touching the GPU and relays rank 0's JSON line; launched under torch.distributed.run (WORLD_SIZE set) it is one of the ranks.
@@ -32,6 +36,7 @@ HAZARDS = {0.5: 0.006402303360855854, 1.0: 0.01553038972325307, 2.0: 0.009729741
            4.0: 0.021196186202801115, 5.0: 0.02284319986706472, 7.0: 0.010111423894480876, 10.0: 0.00613267811172937,
            15.0: 0.0036969930706003337, 20.0: 0.003791311459217732}
 HBM_PEAK_GBS = 8000.0                               # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+STRONG_TOTAL_PATHS = 1 << 20                       # the metric's configuration: 1 M paths x 250 steps in total
 REF_CVA, REF_CVA_SE = 0.004623, 0.000012            # the reference itself on this workload at 50 k + 50 k paths
 KERNEL_SOURCES = ["kf_lean.hip", "kf_common.h", "mcx_device.h", "mcx_math.h", "mcx_tables.h", "k1_paths.hip"]   # what the timed kernels are compiled from
 
@@ -115,6 +120,8 @@ def main():
     ap.add_argument("--presim", type=int, default=131072, help="pre-simulation (LSM) paths PER GPU (weak) / in total (strong)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-strong", action="store_true", help="skip the extra timed region on 1,048,576 paths in total")
+    ap.add_argument("--sustain", type=float, default=1.0, help="seconds of the second (long) timed region; 0: off")
     ap.add_argument("--clock-warmup", type=float, default=1.0, help="seconds of untimed passes before the W warm-up steps (power state)")
     ap.add_argument("--plan", default="auto", choices=["auto", "semi", "fused", "unfused"],
                     help="main-pass execution plan: fused = one launch; semi = K1 + one book/metric kernel; unfused = K1,K2,K4")
@@ -187,69 +194,99 @@ def main():
     # A GPU that sat idle through minutes of imports is in a low power state and needs about a second of load to reach its
     # clocks; W warm-up passes of ~1 ms each do not get it there.  Run the same pass untimed for --clock-warmup seconds first.
     # (a fixed pass count agreed by all ranks: every pass holds a collective, a time-based loop would not match across ranks)
-    n_clock = int(args.clock_warmup / max(plan_ms[best] * 1e-3, 1e-4))
-    if grouped:
-        tc = torch.tensor([n_clock], dtype=torch.int64, device="cuda")
-        dist.broadcast(tc, 0)
-        n_clock = int(tc.item())
+    def agree(n):
+        if grouped:
+            tc = torch.tensor([n], dtype=torch.int64, device="cuda")
+            dist.broadcast(tc, 0)
+            n = int(tc.item())
+        return n
+
+    n_clock = agree(int(args.clock_warmup / max(plan_ms[best] * 1e-3, 1e-4)))
     for _ in range(n_clock):
         sc.main_pass(paths_buf if best != "fused" else None)
-    for _ in range(args.warmup):
-        res = sc.main_pass(paths_buf if best != "fused" else None)
-    # device time of the dominant kernel with HIP events on the launch stream (torch's current stream = the stream the
-    # library launches on, _native.HipBackend._stream)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     fused = best == "fused"
-    # one-launch plan: two passes in flight — the record gather over RCCL (under a process group), the copy to the host and the
-    # merge of pass k run while the kernel of pass k+1 computes (controller.fused_pass_begin / fused_pass_end); every pass still
-    # delivers its merged result inside the timed region.  One GPU without a group: the records land in pinned host memory
-    # directly; 1.075-1.080 ms per pass against 1.082-1.087 for the pass that waits for its result before the next launch, and
-    # the same code path as N > 1.
-    pipelined = fused and sc.pipelined_passes_available() and not os.environ.get("MCX_BENCH_NO_PIPELINE")
-    pending = None
-    # the one-launch kernel is timed by the library itself: HIP event pairs recorded around its launch on the launch stream
-    # (mcx_fused_set_timing), so that the figure is the kernel alone and not kernel + the 5 us record merge that follows it
-    lib_timing = fused and hasattr(be, "fused_set_timing")
-    if lib_timing:
-        # every 4th timed step carries the event pair (a pair costs ~8 us of stream time per step: 1.088 vs 1.079 ms measured)
-        be.fused_set_timing(sc._fused, 4 if args.steps >= 8 else 1)
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        if not lib_timing:
-            ev[k][0].record()
-        if pipelined:
-            ticket = sc.fused_pass_begin()
-            if pending is not None:
-                res = sc.fused_pass_end(pending)
-            pending = ticket
-        elif fused:
-            res = sc._fused_pass()               # one launch (+ block merge, record copy, rank gather)
-            if not lib_timing:
-                ev[k][1].record()
-        elif best == "semi":
-            paths = sc._main_engine.generate_paths_native(out=paths_buf)
-            ev[k][1].record()                    # K1 device time; then ONE kernel for book + metrics
-            res = sc._finish_fused_records(be.fused_eval_paths(sc._fused, paths))
-        else:
-            paths = sc._main_engine.generate_paths_native(out=paths_buf)
-            ev[k][1].record()
-            cfs, expo = be.eval_book(sc.book, paths)
-            res = sc._evaluate_all(sc._shard, cfs, expo, paths)
-    if pending is not None:
-        res = sc.fused_pass_end(pending)
-    barrier()
-    dt = time.perf_counter() - t0
-    if grouped:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    if lib_timing:
-        tk = be.fused_kernel_times(sc._fused)
-        k1_ms = float(np.mean(tk)) if tk.size else float("nan")        # (the first 64 steps when --steps is larger)
-        be.fused_set_timing(sc._fused, 0)
-    else:
-        k1_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    def timed_passes(sc, n_steps, warmup, want_kernel_ms):
+        """W untimed + exactly n_steps timed passes of controller `sc` between barriers; returns (seconds [max over ranks], last
+        result, kernel ms or nan).  One-launch plan: two passes in flight — the record gather over RCCL (under a process group), the
+        copy to the host and the merge of pass k run while the kernel of pass k+1 computes (controller.fused_pass_begin /
+        fused_pass_end); every pass still delivers its merged result inside the timed region.  One GPU without a group: the
+        records land in pinned host memory directly; the same code path as N > 1."""
+        res = None
+        for _ in range(warmup):
+            res = sc.main_pass(paths_buf if best != "fused" else None)
+        # device time of the dominant kernel with HIP events on the launch stream (torch's current stream = the stream the
+        # library launches on, _native.HipBackend._stream)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_steps if want_kernel_ms else 0)]
+        pipelined = fused and sc.pipelined_passes_available() and not os.environ.get("MCX_BENCH_NO_PIPELINE")
+        pending = None
+        # the one-launch kernel is timed by the library itself: HIP event pairs recorded around its launch on the launch stream
+        # (mcx_fused_set_timing), so that the figure is the kernel alone and not kernel + the 5 us record merge that follows it
+        lib_timing = want_kernel_ms and fused and hasattr(be, "fused_set_timing")
+        if lib_timing:
+            # every 4th timed step carries the event pair (a pair costs ~8 us of stream time per step: 1.088 vs 1.079 ms measured)
+            be.fused_set_timing(sc._fused, 4 if n_steps >= 8 else 1)
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(n_steps):
+            if want_kernel_ms and not lib_timing:
+                ev[k][0].record()
+            if pipelined:
+                ticket = sc.fused_pass_begin()
+                if pending is not None:
+                    res = sc.fused_pass_end(pending)
+                pending = ticket
+            elif fused:
+                res = sc._fused_pass()               # one launch (+ block merge, record copy, rank gather)
+                if want_kernel_ms and not lib_timing:
+                    ev[k][1].record()
+            elif best == "semi":
+                paths = sc._main_engine.generate_paths_native(out=paths_buf)
+                if want_kernel_ms:
+                    ev[k][1].record()                # K1 device time; then ONE kernel for book + metrics
+                res = sc._finish_fused_records(be.fused_eval_paths(sc._fused, paths))
+            else:
+                paths = sc._main_engine.generate_paths_native(out=paths_buf)
+                if want_kernel_ms:
+                    ev[k][1].record()
+                cfs, expo = be.eval_book(sc.book, paths)
+                res = sc._evaluate_all(sc._shard, cfs, expo, paths)
+        if pending is not None:
+            res = sc.fused_pass_end(pending)
+        barrier()
+        dt = time.perf_counter() - t0
+        if grouped:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        k_ms = float("nan")
+        if lib_timing:
+            tk = be.fused_kernel_times(sc._fused)
+            k_ms = float(np.mean(tk)) if tk.size else float("nan")        # (the first 64 steps when --steps is larger)
+            be.fused_set_timing(sc._fused, 0)
+        elif want_kernel_ms:
+            k_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        return dt, res, k_ms, pipelined
+
+    dt, res, k1_ms, pipelined = timed_passes(sc, args.steps, args.warmup, True)
+    # a second timed region of >= 1 s of the same passes: K = 20 steps of 1 ms are 20 ms, too short for an outside clock to check
+    n_long = agree(max(args.steps, int(math.ceil(args.sustain / max(dt / args.steps, 1e-5))))) if args.sustain > 0 else 0
+    sustained = None
+    if n_long:
+        dt_long, _, _, _ = timed_passes(sc, n_long, 0, False)
+        sustained = {"steps": n_long, "seconds": dt_long, "ms_per_step": dt_long / n_long * 1e3,
+                     "value": (sc._main_engine.num_paths * world if world == 1 else per_gpu * world) * S * n_long / dt_long}
+    # the metric's own configuration: 1,048,576 paths IN TOTAL over the N GPUs (strong scaling), same K steps, same loop
+    strong = None
+    if args.scaling == "weak" and fused and not args.no_strong and (world > 1 or per_gpu != STRONG_TOTAL_PATHS):
+        sp, spre = STRONG_TOTAL_PATHS // world, max(args.presim // world, 4096)
+        sc_s = build_controller(sp * world, spre * world, be)
+        sc_s.prepare()
+        sc_s.main_pass()
+        dt_s, res_s, k_s, _ = timed_passes(sc_s, args.steps, args.warmup, True)
+        strong = {"total_paths": sp * world, "paths_per_gpu": sp, "ms_per_step": dt_s / args.steps * 1e3, "kernel_ms": k_s,
+                  "value": sp * world * S * args.steps / dt_s, "cva": res_s[0][0][0][0], "mc_error": res_s[0][0][0][1]}
+        del sc_s
 
     if rank == 0:
         cva, err = res[0][0][0]
@@ -298,14 +335,17 @@ def main():
             "config": {"workload": "Vasicek+CIR++ (rho=0.5) payer IRS CVA, Euler, 51 dates x 5 sub-steps (SURVEY §8d config 3)",
                        "paths_per_gpu": n_local, "steps_per_path": S, "state_dim": D, "stored_dates": T,
                        "exposure_dates": E, "presim_paths_per_gpu": pre_gpu, "parallelism": f"paths x{world}",
+                       "total_paths": total_paths, "value_is": f"{args.scaling} scaling: {total_paths} paths in total ({n_local} per GPU)",
                        "execution_plan": best, "plan_probe_ms": plan_ms,
                        "passes_in_flight": 2 if pipelined else 1},
-            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "strong": strong, "sustained": sustained,
+            "roofline": {"bound": "hbm", "binding_resource": "f64 VALU issue (see `alu`)" if fused else "f64 VALU issue", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": k1_ms,
                          "algorithmic_bytes_per_launch": k1_bytes,
                          "note": "achieved = ALGORITHMIC bytes of the pass (SURVEY §8d: 4096 B/path, what the unfused dataflow "
-                                 "moves) / kernel time; the fused kernel materialises nothing (`traffic` = measured HBM bytes) and "
-                                 "is bound by f64 VALU issue: see `alu`"},
+                                 "moves) / kernel time, i.e. an HBM-roofline EQUIVALENT: the fused kernel materialises none of these bytes "
+                                 "(`traffic` = measured HBM bytes) and the resource that binds it is f64 VALU issue — `alu.frac` is the "
+                                 "fraction of THAT bound"},
             "alu": alu,
             "result": {"cva": cva, "mc_error": err, "z_vs_reference": (cva - REF_CVA) / math.hypot(err, REF_CVA_SE),
                        "reference_cva": REF_CVA, "reference_mc_error": REF_CVA_SE},

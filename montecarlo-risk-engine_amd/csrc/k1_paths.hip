@@ -167,6 +167,10 @@ extern "C" int mcx_sim_create(mcx_handle* h, const mcx_sim_desc* d, mcx_sim** ou
     for (int k = 0; k < d->n_steps; ++k) {
         if (d->steps[k].store_idx >= d->n_dates || d->steps[k].chol_idx < 0 || d->steps[k].chol_idx >= d->n_chol)
             MCX_FAIL(h, -5, "mcx_sim_create: step %d references date/cholesky out of range", k);
+        // EULER / QE correlate every sub-step with the factor of the one correlation matrix (model.py:66-73): the kernels read
+        // factor 0 without waiting for the step record
+        if ((d->scheme == MCX_SCHEME_EULER || d->scheme == MCX_SCHEME_QE) && d->steps[k].chol_idx != 0)
+            MCX_FAIL(h, -5, "mcx_sim_create: step %d: the EULER / QE schemes use Cholesky factor 0 for every sub-step", k);
     }
     MCX_HIP(h, hipSetDevice(h->device));
     mcx_sim* sim = new mcx_sim();

@@ -370,8 +370,20 @@ __global__ __launch_bounds__(MCX_BLOCK, MCX_LEAN_WAVES) void kf_lean(const Fused
 #pragma unroll 1
                 while (st < 0 && step < n_steps) {
                     if constexpr (RU == 1) {
+                        // draws of all the lane's paths in ONE basic block (unguarded root, pair_from_words), one rare branch for the
+                        // 2^-32 draws that may round to u = 1, then the state updates
+                        double zz[PPL][NZ], uu[PPL];
+                        bool rare = false;
+                        if constexpr (INJECT) {
 #pragma unroll
-                        for (int q = 0; q < PPL; ++q) sim_substep<NSLOT, NZ, INJECT, SIG, BMB, true>(k, step, path[q], i[q], reg[q], tab, seed, bc, &vc);   // POS: mcx_fused_create
+                            for (int q = 0; q < PPL; ++q) sim_draw<NZ, true, SIG, BMB>(k, step, path[q], i[q], zz[q], uu[q], tab, seed, bc, &vc);
+                        } else rare = sim_draw_n<PPL, NZ, SIG, BMB>(k, step, path, zz, uu, tab, seed, bc, vc);
+                        if (!INJECT && __builtin_expect(__any(rare), 0)) {
+#pragma unroll
+                            for (int q = 0; q < PPL; ++q) sim_draw<NZ, false, SIG, BMB, true>(k, step, path[q], i[q], zz[q], uu[q], tab, seed, bc, &vc);
+                        }
+#pragma unroll
+                        for (int q = 0; q < PPL; ++q) st = sim_apply<NSLOT, NZ, SIG, true>(k, step, reg[q], zz[q], uu[q]);   // POS: mcx_fused_create
                     } else {
                         if (pos == RU) {
                             // refill: the draws of sub-steps step .. step + RU - 1 (counters beyond the last sub-step are drawn and dropped)
@@ -392,11 +404,10 @@ __global__ __launch_bounds__(MCX_BLOCK, MCX_LEAN_WAVES) void kf_lean(const Fused
                             double zz[NZ];
 #pragma unroll
                             for (int j = 0; j < NZ; ++j) zz[j] = zr[q][pos * NZ + j];          // wave-uniform index: M0-relative register read
-                            sim_apply<NSLOT, NZ, SIG, true>(k, step, reg[q], zz, QE_U ? ur[q][pos] : 0.0);
+                            st = sim_apply<NSLOT, NZ, SIG, true>(k, step, reg[q], zz, QE_U ? ur[q][pos] : 0.0);
                         }
                         ++pos;
                     }
-                    st = ldk(&k.steps[step].store_idx);
                     ++step;
                 }
             }

@@ -125,8 +125,12 @@ __device__ __forceinline__ double dev_barrier_event(const DevEvent& e, const Dev
 // one draw = two uniforms in (0,1) and their Box-Muller pair (include/mcx.h "RNG contract")
 // TAB: `tab` is the block's LDS copy of the Box-Muller tables (mcx_bm_load); otherwise polynomial log / sincos
 // the four words of one Philox block -> first uniform + Box-Muller pair (what mcx_box_muller exposes for tests)
-template <bool TAB = false, int BMB = 7>
-__device__ __forceinline__ void pair_from_words(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, double& ua, double& z0, double& z1,
+// GUARD = false (kf_lean.hip): the root is taken unguarded and the function returns whether this lane's draw is one of the 2^-32
+// whose high word is all ones — the only ones that can round to u = 1, where the unguarded root may be NaN.  The caller then repeats
+// such a draw with GUARD = true behind ONE rare branch placed after the draws of all its paths, so that the common path is a single
+// basic block in which the scheduler can overlap the table reads of one path with the arithmetic of the other.
+template <bool TAB = false, int BMB = 7, bool GUARD = true>
+__device__ __forceinline__ bool pair_from_words(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, double& ua, double& z0, double& z1,
                                                 const double* __restrict__ tab, const mcx_bm_coef& bc, const mcx_bm_vconst* vc = nullptr)
 {
     ua = u53(w0, w1, vc);
@@ -137,7 +141,8 @@ __device__ __forceinline__ void pair_from_words(uint32_t w0, uint32_t w1, uint32
         // rounding residual of either sign and the unguarded root may return NaN.  u = 1 needs the high word all ones: a wave that
         // holds such a lane (one in 10^8 wave-steps) takes the guarded path; the common path pays one integer compare.
         const double r2 = mcx_m2log_tab<BMB>(ua, tab, bc, vc);
-        if (__builtin_expect(__any(w1 == 0xffffffffu), 0)) r = ua < 1.0 ? mcx_sqrt_g(r2) : 0.0;
+        if (!GUARD) r = mcx_sqrt_gp(r2);
+        else if (__builtin_expect(__any(w1 == 0xffffffffu), 0)) r = ua < 1.0 ? mcx_sqrt_g(r2) : 0.0;
         else r = mcx_sqrt_gp(r2);
         // second uniform u = ((x >> 11) + 0.5) 2^-53, x = w3:w2: its top BMB bits are the table cell, the rest is u - j/N
         // (the same conversion on the masked word, exact)
@@ -150,15 +155,16 @@ __device__ __forceinline__ void pair_from_words(uint32_t w0, uint32_t w1, uint32
     }
     z0 = r * c;
     z1 = r * s;
+    return w1 == 0xffffffffu;
 }
 
-template <bool TAB = false, int BMB = 7>
-__device__ __forceinline__ void draw_pair(uint64_t seed, uint64_t path, uint32_t step, uint32_t draw, double& ua, double& z0, double& z1,
+template <bool TAB = false, int BMB = 7, bool GUARD = true>
+__device__ __forceinline__ bool draw_pair(uint64_t seed, uint64_t path, uint32_t step, uint32_t draw, double& ua, double& z0, double& z1,
                                           const double* __restrict__ tab, const mcx_bm_coef& bc, const mcx_bm_vconst* vc = nullptr)
 {
     uint32_t w0, w1, w2, w3;
     philox4x32_10((uint32_t)path, (uint32_t)(path >> 32), step, draw, (uint32_t)seed, (uint32_t)(seed >> 32), w0, w1, w2, w3);
-    pair_from_words<TAB, BMB>(w0, w1, w2, w3, ua, z0, z1, tab, bc, vc);
+    return pair_from_words<TAB, BMB, GUARD>(w0, w1, w2, w3, ua, z0, z1, tab, bc, vc);
 }
 
 template <bool TAB = false>
@@ -343,11 +349,13 @@ __device__ __forceinline__ void step_slots(const KA& k, const mcx_step& sp, cons
 // the draws of one sub-step of a lane's path: NZ standard normals (+ the uniform of the Heston QE step).  They depend on the counter
 // (path, step) only, never on the state: a kernel may draw several sub-steps ahead (kf_lean.hip, small path counts)
 // seed / bc: the Philox key and the Box-Muller coefficients (SGPRs) of the calling code region (mcx_math.h "region zero")
-template <int NZ, bool INJECT, int SIG, int BMB = 7, class KA>
-__device__ __forceinline__ void sim_draw(const KA& k, int step, uint64_t path, int64_t i, double (&z)[NZ], double& u,
+// GUARD = false: see pair_from_words; returns true when the lane's draws must be repeated with GUARD = true
+template <int NZ, bool INJECT, int SIG, int BMB = 7, bool GUARD = true, class KA>
+__device__ __forceinline__ bool sim_draw(const KA& k, int step, uint64_t path, int64_t i, double (&z)[NZ], double& u,
                                          const double* __restrict__ tab, uint64_t seed, const mcx_bm_coef& bc, const mcx_bm_vconst* vc = nullptr)
 {
     u = 0.0;
+    bool rare = false;
     if (INJECT) {
 #pragma unroll
         for (int j = 0; j < NZ; ++j) z[j] = k.inject_z[((int64_t)step * NZ + j) * k.ld + i];
@@ -357,7 +365,7 @@ __device__ __forceinline__ void sim_draw(const KA& k, int step, uint64_t path, i
 #pragma unroll
         for (int q = 0; q < (NZ + 1) / 2; ++q) {
             double z0, z1;
-            draw_pair<true, BMB>(seed, path, (uint32_t)step, (uint32_t)q, ua, z0, z1, tab, bc, vc);
+            rare |= draw_pair<true, BMB, GUARD>(seed, path, (uint32_t)step, (uint32_t)q, ua, z0, z1, tab, bc, vc);
             z[2 * q] = z0;
             if (2 * q + 1 < NZ) z[2 * q + 1] = z1;
         }
@@ -366,17 +374,134 @@ __device__ __forceinline__ void sim_draw(const KA& k, int step, uint64_t path, i
             draw_pair<false>(seed, path, (uint32_t)step, (uint32_t)((NZ + 1) / 2), u, z0, z1, nullptr, bc);
         }
     }
+    return rare;
+}
+
+// ---- the draws of PPL paths, staged for latency (kf_lean.hip) -------------------------------------------------------------------
+// The same arithmetic as draw_pair<true, BMB, false> per path, in an order the backend is made to keep (sched_barrier): (A) the
+// Philox blocks of all paths, round by round; (B) the table cells of both Box-Muller functions of all paths and their LDS reads;
+// (C) everything that needs no table value — the second uniform's remainder, the angle polynomials, the exponent; (D) the rest.
+// Left to itself the backend emits path after path, each `ds_read` followed at once by the wait for it: with one or two waves per
+// SIMD (a GPU's share of a strong-scaled run) nothing covers the LDS latency; here stage C does.
+template <int PPL>
+__device__ __forceinline__ void philox4x32_10_n(const uint64_t (&path)[PPL], uint32_t step, uint32_t draw, uint64_t seed,
+                                                uint32_t (&o0)[PPL], uint32_t (&o1)[PPL], uint32_t (&o2)[PPL], uint32_t (&o3)[PPL])
+{
+    uint32_t c0[PPL], c1[PPL], c2[PPL], c3[PPL];
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) { c0[q] = (uint32_t)path[q]; c1[q] = (uint32_t)(path[q] >> 32); c2[q] = step; c3[q] = draw; }
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) {
+            const uint64_t p0 = (uint64_t)0xD2511F53u * c0[q];
+            const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2[q];
+            const uint32_t n0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c1[q], k0, 0x96);
+            const uint32_t n2 = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c3[q], k1, 0x96);
+            c1[q] = (uint32_t)p1; c3[q] = (uint32_t)p0; c0[q] = n0; c2[q] = n2;
+        }
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) { o0[q] = c0[q]; o1[q] = c1[q]; o2[q] = c2[q]; o3[q] = c3[q]; }
+}
+
+// returns whether some path's first uniform may have rounded to 1 (high word all ones): the caller repeats the draws guarded
+template <int PPL, int BMB>
+__device__ __forceinline__ bool draw_pairs_staged(uint64_t seed, const uint64_t (&path)[PPL], uint32_t step, uint32_t draw,
+                                                  double (&z0)[PPL], double (&z1)[PPL], const double* __restrict__ tab,
+                                                  const mcx_bm_coef& C, const mcx_bm_vconst& vc)
+{
+    constexpr int N = 1 << BMB, LOG_TERMS = mcx_bm_shape<BMB>::LOG_TERMS;
+    uint32_t w0[PPL], w1[PPL], w2[PPL], w3[PPL];
+    philox4x32_10_n<PPL>(path, step, draw, seed, w0, w1, w2, w3);
+    double m[PPL], ed[PPL], ps[PPL], pc[PPL];
+    int e[PPL];
+    mcx_d2 tc[PPL], sc[PPL];
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) {                                     // (B) cells and table reads: mcx_m2log_tab, mcx_sincos2pi_tab
+        const double ua = u53(w0[q], w1[q], &vc);
+        m[q] = __builtin_amdgcn_frexp_mant(ua);
+        e[q] = __builtin_amdgcn_frexp_exp(ua);
+        const int jl = (__double2hiint(m[q]) >> (20 - BMB)) & (N - 1);
+        tc[q] = ((const mcx_d2*)tab)[jl];
+        sc[q] = ((const mcx_d2*)(tab + 2 * N))[(int)(w3[q] >> (32 - BMB))];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) {                                     // (C) no table value needed
+        const double ur = u53(w2[q], w3[q] & ((1u << (32 - BMB)) - 1u), &vc);
+        const double d = fma(ur, 6.28318530717958647692, vc.trig_off);
+        const double d2 = d * d;
+        double qs, qc;
+        if constexpr (mcx_bm_shape<BMB>::TRIG_TERMS == 3) {
+            qs = fma(fma(vc.sin_head, d2, C.c[7]), d2, C.c[6]);
+            qc = fma(fma(vc.cos_head, d2, C.c[10]), d2, C.c[9]);
+        } else {
+            qs = fma(vc.sin_head, d2, C.c[6]);
+            qc = fma(vc.cos_head, d2, C.c[9]);
+        }
+        ps[q] = fma(d * d2, qs, d);
+        pc[q] = fma(d2, qc, 1.0);
+        ed[q] = (double)e[q];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    bool rare = false;
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) {                                     // (D) radius and rotation
+        const double s = fma(m[q], tc[q].x, 2.0);
+        double p = vc.log_head;
+#pragma unroll
+        for (int k = LOG_TERMS - 2; k >= 0; --k) p = fma(p, s, C.c[k]);
+        const double r2 = fma(ed[q], -2.0 * 6.93147180559945309417e-01, tc[q].y) + fma(s * s, p, s);
+        const double r = mcx_sqrt_gp(r2);
+        const double sn = fma(sc[q].x, pc[q], sc[q].y * ps[q]);
+        const double cs = fma(-sc[q].x, ps[q], sc[q].y * pc[q]);
+        z0[q] = r * cs;
+        z1[q] = r * sn;
+        rare |= w1[q] == 0xffffffffu;
+    }
+    return rare;
+}
+
+// the draws of one sub-step for the PPL paths of a lane (sim_draw per path, the normals through draw_pairs_staged)
+template <int PPL, int NZ, int SIG, int BMB, class KA>
+__device__ __forceinline__ bool sim_draw_n(const KA& k, int step, const uint64_t (&path)[PPL], double (&z)[PPL][NZ], double (&u)[PPL],
+                                           const double* __restrict__ tab, uint64_t seed, const mcx_bm_coef& bc, const mcx_bm_vconst& vc)
+{
+    bool rare = false;
+#pragma unroll
+    for (int dq = 0; dq < (NZ + 1) / 2; ++dq) {
+        double a[PPL], b[PPL];
+        rare |= draw_pairs_staged<PPL, BMB>(seed, path, (uint32_t)step, (uint32_t)dq, a, b, tab, bc, vc);
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) { z[q][2 * dq] = a[q]; if (2 * dq + 1 < NZ) z[q][2 * dq + 1] = b[q]; }
+    }
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) {
+        u[q] = 0.0;
+        if (sig_scheme(SIG) == MCX_SCHEME_QE || (sig_scheme(SIG) < 0 && k.n_uniform)) {
+            double t0, t1;
+            draw_pair<false>(seed, path[q], (uint32_t)step, (uint32_t)((NZ + 1) / 2), u[q], t0, t1, nullptr, bc);
+        }
+    }
+    return rare;
 }
 
 // the state update of one sub-step from its draws: Cholesky, per-slot maps.  reg[2s], reg[2s+1] = state of slot s.
+// Returns the timeline date stored after this sub-step (mcx_step::store_idx, -1: none) — from the SAME record load as dt, so that
+// the loop condition of the caller does not wait for a second scalar load at the end of every sub-step.
 template <int NSLOT, int NZ, int SIG, bool POS = false, class KA>
-__device__ __forceinline__ void sim_apply(const KA& k, int step, double (&reg)[2 * NSLOT], const double (&z)[NZ], double u)
+__device__ __forceinline__ int sim_apply(const KA& k, int step, double (&reg)[2 * NSLOT], const double (&z)[NZ], double u)
 {
     const mcx_step sp = ldk_struct(&k.steps[step]);    // wave-uniform -> scalar loads
     double zc[NZ];
-    const double* __restrict__ L = k.chol + (int64_t)sp.chol_idx * NZ * NZ;     // model.py:48  z @ chol.T
-    // EULER / QE correlate with the factor of a CORRELATION matrix (model.py:66-73): its first entry is sqrt(1) = 1 exactly
+    // EULER / QE correlate with the factor of a CORRELATION matrix (model.py:66-73): its first entry is sqrt(1) = 1 exactly, and
+    // there is ONE factor for the whole run (mcx_sim_create checks chol_idx == 0): its address does not wait for the step record
     constexpr bool UNIT_L00 = sig_scheme(SIG) == MCX_SCHEME_EULER || sig_scheme(SIG) == MCX_SCHEME_QE;
+    const double* __restrict__ L = UNIT_L00 ? k.chol : k.chol + (int64_t)sp.chol_idx * NZ * NZ;     // model.py:48  z @ chol.T
 #pragma unroll
     for (int r = 0; r < NZ; ++r) {
         double acc = (UNIT_L00 && r == 0) ? z[0] : ldk(L + r * NZ) * z[0];
@@ -386,6 +511,7 @@ __device__ __forceinline__ void sim_apply(const KA& k, int step, double (&reg)[2
     }
     const double* __restrict__ ax = k.aux + (int64_t)step * NSLOT * MCX_AUX;
     step_slots<NSLOT, NZ, SIG, 0, POS>(k, sp, ax, reg, zc, u);
+    return sp.store_idx;
 }
 
 // one sub-step of the whole model for a lane: draws, Cholesky, per-slot maps

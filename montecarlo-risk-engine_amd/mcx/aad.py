@@ -70,7 +70,7 @@ def run_with_tangents(sc):
     _check_supported(sc)
     t0 = time.perf_counter()
     be = sc.backend
-    shard = Shard()
+    shard = sc.shard_factory()
     model = sc.model
     plan = SimPlan(model, sc.simulation_timeline.numpy(), sc.simulation_scheme, sc.num_steps)
     sim = be.sim_create(plan)
@@ -298,7 +298,7 @@ def run_with_tangent_book(sc):
     if any(sc._can_skip_monte_carlo_for_product(p) for p in sc.products):
         raise _NoTangentForm("analytic shortcuts")
     t0 = time.perf_counter()
-    be, shard = sc.backend, Shard()
+    be, shard = sc.backend, sc.shard_factory()
     NP = _abi.TANGENT_NP
     base = _clone_controller(sc, sc.model, sc.reference_float32_cf_cache)
     res0 = base.run_simulation()

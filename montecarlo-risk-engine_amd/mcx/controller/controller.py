@@ -743,12 +743,16 @@ class SimulationController:
         res = metric.evaluate(exposures=exposures, cfs=cf, resolved_requests=resolved, netting_set=ns, model=self.model)
         return [(float(v), float(e)) for v, e in res]
 
+    # the path shard of this process: torch.distributed's default group (mcx/parallel.py).  Tests replace the factory by an
+    # in-process stand-in that emulates several ranks on one GPU (tests/emulated_ranks.py).
+    shard_factory = Shard
+
     # ---- entry point (controller.py:663-709) ------------------------------------------------------------------------
     def prepare(self):
         """everything before the main simulation: descriptor compilation + (if needed) pre-simulation and LSM regression
         (the reference's perform_prepocessing, controller.py:257-292)"""
         be = self.backend
-        self._shard = Shard()
+        self._shard = self.shard_factory()
         self.last_state = {}             # release the previous run's device buffers first: the allocator can reuse them
         t0 = time.perf_counter()
         self._compile_all()
@@ -866,7 +870,6 @@ class SimulationController:
         return self._shard.device_collectives or self._shard.world == 1
 
     def fused_pass_begin(self):
-        import torch.distributed as dist
         be, f, eng, sh = self.backend, self._fused, self._main_engine, self._shard
         pipe = self.__dict__.setdefault("_pipe", dict(slot=0, busy=[False, False], side=torch.cuda.Stream(device=be.device), host={}))
         slot = pipe["slot"]
@@ -894,7 +897,7 @@ class SimulationController:
         with torch.cuda.stream(pipe["side"]):
             pipe["side"].wait_event(launched)
             g = self._buffer(f"pipe_gather{slot}", sh.world, n_rec, 4)
-            dist.all_gather_into_tensor(g, rec, group=sh.group)                    # RCCL orders itself after the side stream
+            sh.all_gather_into(g, rec)                                             # RCCL orders itself after the side stream
             host.copy_(g, non_blocking=True)
             done = torch.cuda.Event()
             done.record()

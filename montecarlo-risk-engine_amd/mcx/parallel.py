@@ -68,6 +68,11 @@ class Shard:
         dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
         return out
 
+    def all_gather_into(self, out: torch.Tensor, t: torch.Tensor) -> None:
+        """the same collective into a caller-owned [world, *t.shape] device buffer, on the CURRENT stream (the pipelined passes
+        of the controller issue it on a side stream)"""
+        dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
+
     def all_gather_np(self, a: np.ndarray) -> np.ndarray:
         """stack equal-shaped float64 arrays of all ranks along a new leading axis (the single small collective that
         carries the (n, shift, s1, s2) accumulator records of every metric)"""

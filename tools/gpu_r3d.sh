@@ -1,0 +1,16 @@
+#!/bin/bash
+O=$PWD/gpurun_out/r3d; mkdir -p $O
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; rc=$?; tail -5 $O/pytest.log; [ $rc -ne 0 ] && exit $rc
+for p in 131072 262144 1048576; do
+  for sh in 21 11; do
+    MCX_LIB_PATH=$PWD/variants/libmcx_ab.so MCX_LEAN_SHAPE=$sh timeout -k 10 120 python bench.py --paths $p --no-cpu-baseline --no-strong --sustain 0 --plan fused --steps 40 > $O/b_${p}_$sh.json 2> $O/b_${p}_$sh.err || exit 1
+    python3 - $O/b_${p}_$sh.json $p $sh <<'PY'
+import json,sys
+d=json.load(open(sys.argv[1])); print("paths %s shape %s  ms/step %.4f kernel_ms %.4f cva %.10f" % (sys.argv[2], sys.argv[3], d["ms_per_step"], d["roofline"]["kernel_ms"], d["result"]["cva"]), flush=True)
+PY
+  done
+done
+timeout -k 10 300 python bench.py > $O/bench_default.json 2> $O/bench_default.err; python3 - $O/bench_default.json <<'PY'
+import json,sys
+d=json.load(open(sys.argv[1])); print("default: ms/step %.4f kernel_ms %.4f value %.4e strong %s sustained %s" % (d["ms_per_step"], d["roofline"]["kernel_ms"], d["value"], d["strong"], d["sustained"]))
+PY
