@@ -143,7 +143,18 @@ def main():
     grouped = "WORLD_SIZE" in os.environ                # under torch.distributed.run (also with one rank): RCCL process group
     if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL prints a version banner on stdout when its first communicator comes up: keep stdout for the ONE JSON line
+        sys.stdout.flush()
+        saved_out = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_out, 1)
+            os.close(saved_out)
 
     from mcx import _native
     be = _native.HipBackend(local_rank)

@@ -1,6 +1,7 @@
 // kf_common.h — records and device helpers shared by the fused main-pass kernels (kf_fused.hip: event interpreter and
 // evaluation-from-paths pass; kf_lean.hip: the straight-line one-launch kernel).  gfx950 only.
 #pragma once
+#include <cstddef>
 #include "mcx_device.h"
 
 
@@ -35,6 +36,7 @@ struct ChunkHeader { int32_t n_ev, n_mop, n_terms, bytes; };
 // optional threshold / EPE-ENE record / CVA increment).  Such a date runs ~130 instructions of branch-light code with every
 // control field in SGPRs instead of ~500 instructions of event interpretation; any other date uses the interpreter.
 struct FastDate {
+    // ---- hot head (FastDateHot below is a view of these 144 bytes: ONE batch of scalar loads at the top of a date) ----
     int32_t valid, flags;            // valid: 0 interpreted, 1 straight-line in every fused kernel, 2 straight-line in kf_lean only
                                      // (exercise event / state-dependent exposure: flags 128 / 256)
                                      // flags: 1 cash, 2 expo, 4 cva, 8 profile, 16 constant numeraire, 32 metric op present,
@@ -42,14 +44,15 @@ struct FastDate {
                                      //     no EPE / ENE record on this date
     int32_t ni_reg, lin_reg, n_exp, x_reg, coeff_off0, coeff_off1, rec_profile, s_reg, c_reg, pad;
     int32_t t_reg[4];
+    double x_a, x_d;                 // explanatory x = x_a + x_d * reg[x_reg]
+    double c_a, c_b, c_c0, c_c1;     // S(t,t+) cond = c_a + c_b exp(c_c0 + c_c1 reg[c_reg])
+    double m_b, m_c0, m_n1, m_s1;    // S(0,t) / numeraire = m_b exp(m_c0 + m_n1 reg[ni_reg] + m_s1 reg[s_reg])   (flag 64)
+    // ---- the rest: read at the point of use ----
     double ni_c0, ni_c1;             // 1/numeraire = exp(ni_c0 + ni_c1 x)   (flag 16: = ni_c0)
     double k0, k1;                   // cash affine part k0 + k1 * reg[lin_reg]
     double t_w[4], t_c0[4], t_c1[4];
-    double x_a, x_d;                 // explanatory x = x_a + x_d * reg[x_reg]
     double thr;
     double s_b, s_c0, s_c1;          // S(0,t)       = s_b exp(s_c0 + s_c1 reg[s_reg])
-    double c_a, c_b, c_c0, c_c1;     // S(t,t+) cond = c_a + c_b exp(c_c0 + c_c1 reg[c_reg])
-    double m_b, m_c0, m_n1, m_s1;    // S(0,t) / numeraire = m_b exp(m_c0 + m_n1 reg[ni_reg] + m_s1 reg[s_reg])   (flag 64)
     // flag 128: exercise event of the book's ONE two-state exercise product (bermudan_option.py:93-131): immediate value
     // max(ex_sign (ex_k0 + ex_k1 reg[ex_lin_reg] + sum_j w_j exp(c0_j + c1_j reg[r_j]) - ex_strike), 0) over the LeanTerm range
     // [ex_term_off, ex_term_off + ex_n); continuation = polynomial (row of state 1 at ex_coeff_off + n_basis) in ex_x_a + ex_x_d reg[ex_x_reg]
@@ -64,6 +67,16 @@ struct FastDate {
     double ex_p_lo, ex_p_hi, ex_p_ms, ex_p_ih;
     int32_t ex_p_off, ex_p_blk, ex_p_reg, ex_p_pad;
 };
+// the head of a FastDate as one record (what a CVA-only date reads: kf_lean.hip lean_date)
+struct FastDateHot {
+    int32_t valid, flags;
+    int32_t ni_reg, lin_reg, n_exp, x_reg, coeff_off0, coeff_off1, rec_profile, s_reg, c_reg, pad;
+    int32_t t_reg[4];
+    double x_a, x_d;
+    double c_a, c_b, c_c0, c_c1;
+    double m_b, m_c0, m_n1, m_s1;
+};
+static_assert(sizeof(FastDateHot) == 144 && offsetof(FastDate, ni_c0) == sizeof(FastDateHot), "FastDateHot must mirror the head of FastDate");
 struct LeanTerm { double w, c0, c1; int32_t reg, pad; };     // w exp(c0 + c1 reg[reg]), read through scalar loads
 
 struct FusedArgs {
@@ -85,6 +98,17 @@ struct FusedArgs {
     double lgd[MCX_FUSED_MAX_NS];
     int32_t init_state[MCX_FUSED_MAX_STATEFUL];
 };
+
+// merge of two (count, mean, centred second moment) triples (Chan, Golub, LeVeque pairwise update)
+__device__ __forceinline__ void chan_merge(double& N, double& mean, double& M2, double n, double m, double q)
+{
+    if (n <= 0.0) return;
+    if (N == 0.0) { N = n; mean = m; M2 = q; return; }
+    const double delta = m - mean, tot = N + n;
+    mean += delta * n / tot;
+    M2 += q + delta * delta * N * n / tot;
+    N = tot;
+}
 
 #define RFL(x) __builtin_amdgcn_readfirstlane(x)
 

@@ -352,16 +352,6 @@ __global__ __launch_bounds__(MCX_BLOCK) void kf_fused(const FusedArgs a)
 // One 256-thread block per record: every thread folds a strided subset of the block records (independent loads in
 // flight), the 256 partial triples are then combined through LDS.  (A one-thread serial merge over 2048 dependent loads
 // took 0.8 ms — a quarter of the whole pass.)
-__device__ __forceinline__ void chan_merge(double& N, double& mean, double& M2, double n, double m, double q)
-{
-    if (n <= 0.0) return;
-    if (N == 0.0) { N = n; mean = m; M2 = q; return; }
-    const double delta = m - mean, tot = N + n;
-    mean += delta * n / tot;
-    M2 += q + delta * delta * N * n / tot;
-    N = tot;
-}
-
 __global__ __launch_bounds__(MCX_BLOCK) void kf_merge(const double* __restrict__ partials, int n_rec, int n_blocks, mcx_acc* __restrict__ out)
 {
     const int r = blockIdx.x;
@@ -813,8 +803,14 @@ static int fused_run_impl(mcx_handle* h, const mcx_fused* f, bool simulate, uint
     int grid;
     const bool timed = f->timing && (f->t_launch++ % f->timing) == 0 && f->t_count < MCX_FUSED_TIMING_RING;
     if (timed) MCX_HIP(h, hipEventRecord(f->tev[2 * f->t_count], s));
+    // host records: the merge writes its few hundred bytes straight into the handle's pinned host buffer (mapped into the
+    // device address space): no copy kernel and no extra dispatch on the stream between the pass and its result
+    const bool direct = !d_out && sizeof(mcx_acc) * (size_t)f->n_rec <= h->pinned_bytes && h->d_pinned_alias;
+    mcx_acc* dst = d_out ? d_out : (direct ? (mcx_acc*)h->d_pinned_alias : f->d_out);
     if (f->lean && (simulate || !inj)) {
         // every date is a straight-line record: the two-paths-per-lane kernel of kf_lean.hip (simulating, or streaming a paths tensor)
+        // (merging the per-block records in the kernel's last block — arrival ticket + device-scope fences — was measured: the
+        //  fences cost ~25 us per launch, three times the kernel boundary they save)
         grid = mcx_launch_kf_lean(a, sd, h->n_cu, inj, simulate, s);
         if (grid < 0) MCX_FAIL(h, MCX_E_NOT_FUSABLE, "not fusable: (slots=%d, z=%d) has no fused instantiation", sd.n_slots, sd.n_z);
     } else {
@@ -845,10 +841,6 @@ static int fused_run_impl(mcx_handle* h, const mcx_fused* f, bool simulate, uint
     }
     MCX_HIP(h, hipGetLastError());
     if (timed) { MCX_HIP(h, hipEventRecord(f->tev[2 * f->t_count + 1], s)); ++f->t_count; }
-    // host records: the merge kernel writes its few hundred bytes straight into the handle's pinned host buffer (mapped into the
-    // device address space): no copy kernel and no extra dispatch on the stream between the pass and its result
-    const bool direct = !d_out && sizeof(mcx_acc) * (size_t)f->n_rec <= h->pinned_bytes && h->d_pinned_alias;
-    mcx_acc* dst = d_out ? d_out : (direct ? (mcx_acc*)h->d_pinned_alias : f->d_out);
     hipLaunchKernelGGL(kf_merge, dim3(f->n_rec), dim3(MCX_BLOCK), 0, s, f->d_partials, f->n_rec, grid, dst);
     MCX_HIP(h, hipGetLastError());
     if (d_out) return 0;

@@ -100,6 +100,46 @@ __device__ __forceinline__ void lean_date(int t, const int64_t (&i)[PPL], const 
     const FastDate* __restrict__ fp = a.fast + t;
     const auto& k = a.k1;
     const mcx_expq_coef ec = mcx_expq_load(zd);       // exponentials: table of 2^(j/128) in LDS + degree-5 remainder
+    // The CVA-only date (the config-3 shape: regression exposure, merged discount x survival factor, conditional default
+    // probability — nothing stored, no cashflow consumer) in TWO rounds of scalar loads instead of one per branch of the general
+    // program below: (1) the head of the record + the arguments, (2) the coefficient rows; and one round of LDS reads for its
+    // two exponentials.  The waits of ~12 dependent scalar loads per date were a third of a wave's cycles at one or two waves
+    // per SIMD.  Same arithmetic as the general path.
+    if (PPL == 1 && !(STORE && k.paths)) {          // (two paths per lane at four waves per SIMD: measured slower — 52 SGPR spills around the date — than the general program below)
+        const FastDateHot hot = ldk_struct((const FastDateHot*)fp);
+        const bool pure_cva = (hot.flags & (64 | 128 | 256 | 2)) == (64 | 2) && !((hot.flags & 1) && (a.cfs != nullptr || a.rec_pv[0] >= 0)) &&
+                              a.expo == nullptr && a.n_basis == 3 && hot.c_b != 0.0;
+        if (pure_cva) {
+            const double* __restrict__ cf = a.coeffs;
+            double c0[3] = {0.0, 0.0, 0.0}, c1[3] = {0.0, 0.0, 0.0};
+            if (hot.coeff_off0 >= 0) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) c0[j] = ldk(cf + hot.coeff_off0 + j);
+            }
+            if (hot.coeff_off1 >= 0) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) c1[j] = ldk(cf + hot.coeff_off1 + j);
+            }
+            double xe[2 * PPL], ev[2 * PPL], p[PPL];
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) {
+                xe[2 * q] = fma(hot.m_s1, reg[q][hot.s_reg], fma(hot.m_n1, reg[q][hot.ni_reg], hot.m_c0));
+                xe[2 * q + 1] = fma(hot.c_c1, reg[q][hot.c_reg], hot.c_c0);
+            }
+            mcx_exp_tab_n<2 * PPL>(xe, ev, etab, ec);
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) {
+                const double x = fma(hot.x_d, reg[q][hot.x_reg], hot.x_a);
+                p[q] = 0.0;
+                if (hot.coeff_off0 >= 0) p[q] += fma(fma(c0[2], x, c0[1]), x, c0[0]);
+                if (hot.coeff_off1 >= 0) p[q] += fma(fma(c1[2], x, c1[1]), x, c1[0]);
+                const double w = hot.m_b * ev[2 * q];
+                const double cs = fma(hot.c_b, ev[2 * q + 1], hot.c_a);
+                cva[q] = fma(fmax(p[q], 0.0), w * (1.0 - cs), cva[q]);
+            }
+            return;
+        }
+    }
     if (STORE && k.paths) {
 #pragma unroll
         for (int q = 0; q < PPL; ++q) if (live[q]) sim_store_state<NSLOT, SIG>(k, t, i[q], reg[q]);
@@ -292,16 +332,14 @@ __device__ __forceinline__ void lean_date(int t, const int64_t (&i)[PPL], const 
 }
 
 #define MCX_LEAN_WAVES 4
-#define MCX_LEAN_RU 4          // sub-steps drawn ahead by the small-path-count shape (launch_lean)
 // SIMULATE = false: the same date programs on a paths tensor produced earlier by K1 (k1.paths is then the INPUT
 // [date][state][path]): one streaming pass, the next date's state columns in flight while this date's program runs
-// RU > 1 (small path counts, launch_lean): the draws of RU consecutive sub-steps are made TOGETHER — they depend on the counter
-// (path, step) only, so a lane that holds one path still offers RU independent Philox / Box-Muller chains to the VALU pipe;
-// the sub-steps then consume them one by one (ring of RU x NZ normals per path, indexed by a wave-uniform position)
-template <int NSLOT, int NZ, bool INJECT, int SIG, int PPL, bool SIMULATE, int RU = 1>
+// (Measured and dropped: drawing the normals of 2-5 sub-steps AHEAD as independent staged chains, for small path counts — the draws
+// depend on the counter (path, step) only.  No gain at one or two waves per SIMD: what a thin launch waits for is scalar work, see
+// launch_lean.)
+template <int NSLOT, int NZ, bool INJECT, int SIG, int PPL, bool SIMULATE>
 __global__ __launch_bounds__(MCX_BLOCK, MCX_LEAN_WAVES) void kf_lean(const FusedArgs)      // read through kargs_region(), never by name
 {
-    static_assert(RU == 1 || (SIMULATE && !INJECT), "drawing ahead needs the counter-based generator");
     constexpr int NREG = 2 * NSLOT;
     constexpr int TILE = MCX_BLOCK * PPL;
     extern __shared__ double lds[];
@@ -352,9 +390,6 @@ __global__ __launch_bounds__(MCX_BLOCK, MCX_LEAN_WAVES) void kf_lean(const Fused
         // ONE date call site: the dates that hold the initial state come first (their sub-step run is empty), then
         // alternately a run of sub-steps up to the next timeline date and that date's program
         int step = 0, t_init = 0;
-        constexpr bool QE_U = sig_scheme(SIG) == MCX_SCHEME_QE || sig_scheme(SIG) < 0;        // the step may consume a uniform
-        double zr[PPL][RU > 1 ? RU * NZ : 1], ur[PPL][RU > 1 && QE_U ? RU : 1];               // draws made ahead (RU > 1)
-        int pos = RU;                                                                         // next unread ring entry; RU: empty
 #pragma unroll 1
         while (true) {
             const bool init = t_init < n_init;
@@ -369,44 +404,29 @@ __global__ __launch_bounds__(MCX_BLOCK, MCX_LEAN_WAVES) void kf_lean(const Fused
                 const mcx_bm_vconst vc = mcx_bm_vconst_make<BMB>(bc);  // constants kept in registers across the run of sub-steps
 #pragma unroll 1
                 while (st < 0 && step < n_steps) {
-                    if constexpr (RU == 1) {
+                    {
                         // draws of all the lane's paths in ONE basic block (unguarded root, pair_from_words), one rare branch for the
                         // 2^-32 draws that may round to u = 1, then the state updates
                         double zz[PPL][NZ], uu[PPL];
                         bool rare = false;
+                        // the scalar loads of this sub-step go out first: the draws below cover their latency
+                        const StepData<NSLOT, NZ> sdat = sim_step_load<NSLOT, NZ, SIG>(k, step);
+                        __builtin_amdgcn_sched_barrier(0);
                         if constexpr (INJECT) {
 #pragma unroll
                             for (int q = 0; q < PPL; ++q) sim_draw<NZ, true, SIG, BMB>(k, step, path[q], i[q], zz[q], uu[q], tab, seed, bc, &vc);
-                        } else rare = sim_draw_n<PPL, NZ, SIG, BMB>(k, step, path, zz, uu, tab, seed, bc, vc);
+                        } else {
+                            uint32_t st_q[PPL];
+#pragma unroll
+                            for (int q = 0; q < PPL; ++q) st_q[q] = (uint32_t)step;
+                            rare = sim_draw_n<PPL, NZ, SIG, BMB>(k, st_q, path, zz, uu, tab, seed, bc, vc);
+                        }
                         if (!INJECT && __builtin_expect(__any(rare), 0)) {
 #pragma unroll
                             for (int q = 0; q < PPL; ++q) sim_draw<NZ, false, SIG, BMB, true>(k, step, path[q], i[q], zz[q], uu[q], tab, seed, bc, &vc);
                         }
 #pragma unroll
-                        for (int q = 0; q < PPL; ++q) st = sim_apply<NSLOT, NZ, SIG, true>(k, step, reg[q], zz[q], uu[q]);   // POS: mcx_fused_create
-                    } else {
-                        if (pos == RU) {
-                            // refill: the draws of sub-steps step .. step + RU - 1 (counters beyond the last sub-step are drawn and dropped)
-#pragma unroll
-                            for (int r = 0; r < RU; ++r)
-#pragma unroll
-                                for (int q = 0; q < PPL; ++q) {
-                                    double zz[NZ], uu;
-                                    sim_draw<NZ, false, SIG, BMB>(k, step + r, path[q], i[q], zz, uu, tab, seed, bc, &vc);
-#pragma unroll
-                                    for (int j = 0; j < NZ; ++j) zr[q][r * NZ + j] = zz[j];
-                                    if (QE_U) ur[q][r] = uu;
-                                }
-                            pos = 0;
-                        }
-#pragma unroll
-                        for (int q = 0; q < PPL; ++q) {
-                            double zz[NZ];
-#pragma unroll
-                            for (int j = 0; j < NZ; ++j) zz[j] = zr[q][pos * NZ + j];          // wave-uniform index: M0-relative register read
-                            st = sim_apply<NSLOT, NZ, SIG, true>(k, step, reg[q], zz, QE_U ? ur[q][pos] : 0.0);
-                        }
-                        ++pos;
+                        for (int q = 0; q < PPL; ++q) st = sim_apply_loaded<NSLOT, NZ, SIG, true>(k, sdat, reg[q], zz[q], uu[q]);   // POS: mcx_fused_create
                     }
                     ++step;
                 }
@@ -467,8 +487,8 @@ __global__ __launch_bounds__(MCX_BLOCK, MCX_LEAN_WAVES) void kf_lean(const Fused
 
 #undef FD
 
-// launch of one (paths per lane, draws made ahead) shape of the kernel; returns the grid
-template <int NSLOT, int NZ, int SIG, int PPL, int RU>
+// launch of one shape (paths per lane) of the kernel; returns the grid
+template <int NSLOT, int NZ, int SIG, int PPL>
 int launch_lean_shape(const FusedArgs& a, int n_cu, bool inject, bool simulate, hipStream_t s)
 {
     const int64_t tiles = (a.k1.n + MCX_BLOCK * PPL - 1) / (MCX_BLOCK * PPL);
@@ -493,11 +513,7 @@ int launch_lean_shape(const FusedArgs& a, int n_cu, bool inject, bool simulate, 
         return (int)((tiles + per - 1) / per);
     };
     int grid;
-    if constexpr (RU > 1) {
-        auto kern = kf_lean<NSLOT, NZ, false, SIG, PPL, true, RU>;
-        grid = sized(residency(kern));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(MCX_BLOCK), lds, s, a);
-    } else if (!simulate) {
+    if (!simulate) {
         auto kern = kf_lean<NSLOT, NZ, false, SIG, PPL, false>;
         grid = sized(residency(kern));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(MCX_BLOCK), lds, s, a);
@@ -521,33 +537,25 @@ void launch_lean(const FusedArgs& a, int n_cu, bool inject, bool simulate, hipSt
     // per CU: 2^19 paths fill the chip once.
     constexpr int PPL = (SIG == SIG_GENERIC && NSLOT >= 2) ? 1 : 2;
 #ifdef MCX_LEAN_AB
-    // tools/build_variants.sh only: every candidate shape, picked by the environment (never defined in the product build)
+    // tools/build_variants.sh only (never defined in the product build): the shape picked by the environment, 10 * PPL + 1
     if (simulate && !inject) {
         const char* sh = getenv("MCX_LEAN_SHAPE");
-        const int code = sh ? atoi(sh) : 0;               // 10 * PPL + RU
-        switch (code) {
-        case 12: *grid_out = launch_lean_shape<NSLOT, NZ, SIG, 1, 2>(a, n_cu, inject, simulate, s); return;
-        case 13: *grid_out = launch_lean_shape<NSLOT, NZ, SIG, 1, 3>(a, n_cu, inject, simulate, s); return;
-        case 14: *grid_out = launch_lean_shape<NSLOT, NZ, SIG, 1, 4>(a, n_cu, inject, simulate, s); return;
-        case 15: *grid_out = launch_lean_shape<NSLOT, NZ, SIG, 1, 5>(a, n_cu, inject, simulate, s); return;
-        case 11: *grid_out = launch_lean_shape<NSLOT, NZ, SIG, 1, 1>(a, n_cu, inject, simulate, s); return;
-        case 22: *grid_out = launch_lean_shape<NSLOT, NZ, SIG, 2, 2>(a, n_cu, inject, simulate, s); return;
-        case 24: *grid_out = launch_lean_shape<NSLOT, NZ, SIG, 2, 4>(a, n_cu, inject, simulate, s); return;
-        case 21: *grid_out = launch_lean_shape<NSLOT, NZ, SIG, 2, 1>(a, n_cu, inject, simulate, s); return;
-        default: break;
-        }
+        const int code = sh ? atoi(sh) : 0;
+        if (code == 11) { *grid_out = launch_lean_shape<NSLOT, NZ, SIG, 1>(a, n_cu, inject, simulate, s); return; }
+        if (code == 21) { *grid_out = launch_lean_shape<NSLOT, NZ, SIG, 2>(a, n_cu, inject, simulate, s); return; }
     }
 #endif
-    // Small path counts (one GPU's share of a strong-scaled run: 2^20 paths over 8 GPUs = 2^17 each): the full shape would leave
-    // one wave per SIMD on a kernel that needs ~8 independent instruction streams per SIMD to keep the VALU pipe issuing.  One path
-    // per lane doubles the waves; drawing MCX_LEAN_RU sub-steps ahead gives each of them that many independent RNG chains.
-    constexpr int RU = MCX_LEAN_RU;
+    // Small path counts (one GPU's share of a strong-scaled run: 2^20 paths over 8 GPUs = 2^17 each): the full shape would put one
+    // wave on a SIMD.  A wave of this kernel spends a third of its cycles on wave-uniform work — scalar loads of the step and date
+    // records and their waits, SALU control (SQ counters, profiles/README.md) — which a second wave on the SIMD overlaps with its
+    // own VALU work and a single wave cannot: below half a chip-filling launch one path per lane (twice the waves) is faster,
+    // 0.176 against 0.195 ms at 131,072 paths, equal at 262,144, slower from there on (the scalar work per path doubles).
     const int64_t full_tiles = (a.k1.n + MCX_BLOCK * PPL - 1) / (MCX_BLOCK * PPL);
-    if (PPL == 2 && simulate && !inject && full_tiles <= (int64_t)2 * n_cu) {
-        *grid_out = launch_lean_shape<NSLOT, NZ, SIG, 1, RU>(a, n_cu, inject, simulate, s);
+    if (PPL == 2 && simulate && !inject && full_tiles < (int64_t)2 * n_cu) {
+        *grid_out = launch_lean_shape<NSLOT, NZ, SIG, 1>(a, n_cu, inject, simulate, s);
         return;
     }
-    *grid_out = launch_lean_shape<NSLOT, NZ, SIG, PPL, 1>(a, n_cu, inject, simulate, s);
+    *grid_out = launch_lean_shape<NSLOT, NZ, SIG, PPL>(a, n_cu, inject, simulate, s);
 }
 
 }  // namespace

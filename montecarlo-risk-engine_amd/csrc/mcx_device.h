@@ -182,6 +182,20 @@ __device__ __forceinline__ double degree_of_truth(double x, bool fuzzy, double e
     return fmin(fmax(v, 0.0), 1.0);
 }
 
+// the aux row of one (sub-step, slot) as the step maps read it: through scalar loads at the point of use (AuxPtr), or from values a
+// kernel loaded AHEAD of the draws of the sub-step (AuxRegs: kf_lean.hip issues the scalar loads of a sub-step before its Philox /
+// Box-Muller stage, whose ~100 VALU instructions then cover their latency — with one or two waves per SIMD nothing else does)
+struct AuxPtr {
+    const double* __restrict__ p;
+    __device__ __forceinline__ double operator[](int i) const { return ldk(p + i); }
+    __device__ __forceinline__ mcx_aux_drv drv() const { return ldk_struct((const mcx_aux_drv*)(p + MCX_AUX_C0)); }
+};
+struct AuxRegs {
+    double v[MCX_AUX];
+    __device__ __forceinline__ double operator[](int i) const { return v[i]; }
+    __device__ __forceinline__ mcx_aux_drv drv() const { mcx_aux_drv d; d.c0 = v[MCX_AUX_C0]; d.c1 = v[MCX_AUX_C1]; d.c2 = v[MCX_AUX_C2]; return d; }
+};
+
 // one sub-step of one sub-model (reference formulas, see oracle/mcx_oracle.c for the line-by-line citations)
 // KIND / SCHEME >= 0 are compile-time constants (specialised kernels: the switch folds away and only the parameters the
 // model really uses stay live in SGPRs); -1 = wave-uniform run-time dispatch (generic kernels).
@@ -189,31 +203,31 @@ __device__ __forceinline__ double degree_of_truth(double x, bool fuzzy, double e
 // a region-local pointer into the kernarg segment, so that every field is a scalar load at its point of use)
 // POS: the caller guarantees a positive CIR++ state at entry (the model's y0 > 0, cirpp.py:40, and the 1e-12 floor after every step):
 // the root of the diffusion then needs no zero test
-template <int KIND, int SCHEME, bool POS = false, class SL>
+template <int KIND, int SCHEME, bool POS = false, class SL, class AUX>
 __device__ __forceinline__ void step_slot(const SL& sl, int scheme_rt, int flags, double dt, double sq,
-                                          const double* __restrict__ aux, double& s0, double& s1, double zc0, double zc1, double u)
+                                          const AUX& aux, double& s0, double& s1, double zc0, double zc1, double u)
 {
     const auto* p = sl.p;
     const int scheme = SCHEME >= 0 ? SCHEME : scheme_rt;
     switch (KIND >= 0 ? KIND : sl.kind) {
     case MCX_MODEL_BS:
         if (scheme == MCX_SCHEME_ANALYTICAL) {
-            s0 = s0 * mcx_exp(ldk(aux + 0) + (zc0 - ldk(aux + 1)));                       // black_scholes.py:61-67
+            s0 = s0 * mcx_exp(aux[0] + (zc0 - aux[1]));                       // black_scholes.py:61-67
         } else {
             // black_scholes.py:79-85, S + (r S dt + sigma S sqrt(dt) z) = S + S (r dt + sigma sqrt(dt) z); the step constants
             // r dt, sigma sqrt(dt) come from the derived entries of the step table (mcx_sim_create)
-            const mcx_aux_drv dc = ldk_struct((const mcx_aux_drv*)(aux + MCX_AUX_C0));
+            const mcx_aux_drv dc = aux.drv();
             s0 = fma(s0, fma(dc.c2, zc0, dc.c0), s0);
         }
         break;
     case MCX_MODEL_VASICEK: {
         const double r = s0;
         s1 = s1 + r * dt;                                                 // left-endpoint integral, vasicek.py:80/107
-        if (scheme == MCX_SCHEME_ANALYTICAL) s0 = (p[2] + (r - p[2]) * ldk(aux + 0)) + zc0;
+        if (scheme == MCX_SCHEME_ANALYTICAL) s0 = (p[2] + (r - p[2]) * aux[0]) + zc0;
         else {
             // r - (a dt) r + sigma sqrt(dt) z + a theta dt as three accumulations INTO the state register (one scalar operand each):
             // the state array is a register tuple indexed by the date programs, a value computed elsewhere would be copied into it
-            const mcx_aux_drv dc = ldk_struct((const mcx_aux_drv*)(aux + MCX_AUX_C0));
+            const mcx_aux_drv dc = aux.drv();
             s0 = fma(dc.c1, r, s0);
             s0 = fma(dc.c2, zc0, s0);
             s0 = s0 + dc.c0;
@@ -223,16 +237,16 @@ __device__ __forceinline__ void step_slot(const SL& sl, int scheme_rt, int flags
     case MCX_MODEL_HW: {
         const double r = s0;
         s1 = s1 + r * dt;
-        if (scheme == MCX_SCHEME_ANALYTICAL) s0 = r * ldk(aux + 0) + ldk(aux + 1) + zc0;
-        else s0 = r + (ldk(aux + 0) - p[3] * r) * dt + p[1] * sq * zc0;
+        if (scheme == MCX_SCHEME_ANALYTICAL) s0 = r * aux[0] + aux[1] + zc0;
+        else s0 = r + (aux[0] - p[3] * r) * dt + p[1] * sq * zc0;
         break;
     }
     case MCX_MODEL_CIRPP: {                                               // cirpp.py:188-198
         const double y = s0;
         const double sy = POS ? mcx_sqrt_gp(y) : mcx_sqrt_g(y);   // = sqrt(clamp(y, 0)) of cirpp.py:194: mcx_sqrt_g returns 0 for y <= 0
         // y - (kappa dt) y + (sigma sqrt(dt)) sqrt(y) z + kappa theta dt, accumulated into the state register (see VASICEK)
-        const mcx_aux_drv dc = ldk_struct((const mcx_aux_drv*)(aux + MCX_AUX_C0));
-        s1 = fma(y + ldk(aux + 0), dt, s1);
+        const mcx_aux_drv dc = aux.drv();
+        s1 = fma(y + aux[0], dt, s1);
         s0 = fma(dc.c1, y, s0);
         s0 = fma(dc.c2 * sy, zc0, s0);
         s0 = s0 + dc.c0;
@@ -240,13 +254,13 @@ __device__ __forceinline__ void step_slot(const SL& sl, int scheme_rt, int flags
         break;
     }
     case MCX_MODEL_CIRPP_DET:                                             // cirpp.py:155-172
-        s1 = s1 + ldk(aux + 0) * dt;
-        s0 = ldk(aux + 1);
+        s1 = s1 + aux[0] * dt;
+        s0 = aux[1];
         break;
     case MCX_MODEL_S2F: {                                                 // schwartz_two_factor.py:147-196; registers (x, y)
         const double x = s0, y = s1;
         if (scheme == MCX_SCHEME_ANALYTICAL) {
-            s0 = x * ldk(aux + 0) + zc0;                                  // short factor: mean reversion + w_x
+            s0 = x * aux[0] + zc0;                                  // short factor: mean reversion + w_x
             s1 = y + p[3] * dt + zc1;                                     // long factor: drift + w_y
         } else {
             s0 = x - p[1] * x * dt + p[2] * sq * zc0;
@@ -266,8 +280,8 @@ __device__ __forceinline__ void step_slot(const SL& sl, int scheme_rt, int flags
         } else {                                                          // heston.py:161-253 (Andersen QE)
             const double eps = 1e-12;
             const bool fuzzy = (flags & MCX_FLAG_SMOOTHING) != 0;
-            const double m = theta + (v - theta) * ldk(aux + 0);
-            const double s2 = v * ldk(aux + 6) + ldk(aux + 7);
+            const double m = theta + (v - theta) * aux[0];
+            const double s2 = v * aux[6] + aux[7];
             const double psi = s2 * mcx_rcp(m * m + eps);
             const double invpsi = mcx_rcp(psi + eps);
             const double t = fmax(2.0 * invpsi - 1.0, 0.0);
@@ -283,9 +297,9 @@ __device__ __forceinline__ void step_slot(const SL& sl, int scheme_rt, int flags
             const double v2 = degree_of_truth(u - pp, fuzzy, 0.3) * v_tail;
             const double w = degree_of_truth(psi - 1.5, fuzzy, 0.5);
             const double vn = (1.0 - w) * v1 + w * v2;
-            const double var_int = fmax(ldk(aux + 4) * v + ldk(aux + 5) * vn, 0.0);
+            const double var_int = fmax(aux[4] * v + aux[5] * vn, 0.0);
             const double vol = mcx_sqrt(fmax(var_int, eps));
-            s0 = logS + rate * dt + ldk(aux + 1) + ldk(aux + 2) * v + ldk(aux + 3) * vn + vol * zc0;
+            s0 = logS + rate * dt + aux[1] + aux[2] * v + aux[3] * vn + vol * zc0;
             s1 = vn;
         }
         break;
@@ -332,8 +346,12 @@ static inline int mcx_sim_signature(const mcx_sim_desc& d)
 }
 
 // compile-time recursion over the slots (the slot index must be a constant expression for the signature lookup)
-template <int NSLOT, int NZ, int SIG, int S, bool POS = false, class KA>
-__device__ __forceinline__ void step_slots(const KA& k, const mcx_step& sp, const double* __restrict__ ax,
+__device__ __forceinline__ AuxPtr aux_of_slot(const double* __restrict__ ax, int s) { return AuxPtr{ax + s * MCX_AUX}; }
+template <int NSLOT>
+__device__ __forceinline__ const AuxRegs& aux_of_slot(const AuxRegs (&ax)[NSLOT], int s) { return ax[s]; }
+
+template <int NSLOT, int NZ, int SIG, int S, bool POS = false, class KA, class AX>
+__device__ __forceinline__ void step_slots(const KA& k, const mcx_step& sp, const AX& ax,
                                            double (&reg)[2 * NSLOT], const double (&zc)[NZ], double u)
 {
     if constexpr (S < NSLOT) {
@@ -341,7 +359,7 @@ __device__ __forceinline__ void step_slots(const KA& k, const mcx_step& sp, cons
         const double zc0 = (NSLOT == 1) ? zc[0] : zc[S < NZ ? S : 0];
         const double zc1 = (NSLOT == 1 && NZ > 1) ? zc[NZ > 1 ? 1 : 0] : 0.0;
         step_slot<sig_kind(SIG, S), sig_scheme(SIG), POS>(k.slots[S], k.scheme, k.flags | k.slots[S].flags, sp.dt, sp.sqrt_dt,
-                                                      ax + S * MCX_AUX, reg[2 * S], reg[2 * S + 1], zc0, zc1, u);
+                                                      aux_of_slot(ax, S), reg[2 * S], reg[2 * S + 1], zc0, zc1, u);
         step_slots<NSLOT, NZ, SIG, S + 1, POS>(k, sp, ax, reg, zc, u);
     }
 }
@@ -383,13 +401,14 @@ __device__ __forceinline__ bool sim_draw(const KA& k, int step, uint64_t path, i
 // (C) everything that needs no table value — the second uniform's remainder, the angle polynomials, the exponent; (D) the rest.
 // Left to itself the backend emits path after path, each `ds_read` followed at once by the wait for it: with one or two waves per
 // SIMD (a GPU's share of a strong-scaled run) nothing covers the LDS latency; here stage C does.
+// (a "chain" is one (path, sub-step) counter: the PPL paths of a lane at one sub-step, or one path at several sub-steps ahead)
 template <int PPL>
-__device__ __forceinline__ void philox4x32_10_n(const uint64_t (&path)[PPL], uint32_t step, uint32_t draw, uint64_t seed,
+__device__ __forceinline__ void philox4x32_10_n(const uint64_t (&path)[PPL], const uint32_t (&step)[PPL], uint32_t draw, uint64_t seed,
                                                 uint32_t (&o0)[PPL], uint32_t (&o1)[PPL], uint32_t (&o2)[PPL], uint32_t (&o3)[PPL])
 {
     uint32_t c0[PPL], c1[PPL], c2[PPL], c3[PPL];
 #pragma unroll
-    for (int q = 0; q < PPL; ++q) { c0[q] = (uint32_t)path[q]; c1[q] = (uint32_t)(path[q] >> 32); c2[q] = step; c3[q] = draw; }
+    for (int q = 0; q < PPL; ++q) { c0[q] = (uint32_t)path[q]; c1[q] = (uint32_t)(path[q] >> 32); c2[q] = step[q]; c3[q] = draw; }
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
@@ -410,7 +429,7 @@ __device__ __forceinline__ void philox4x32_10_n(const uint64_t (&path)[PPL], uin
 
 // returns whether some path's first uniform may have rounded to 1 (high word all ones): the caller repeats the draws guarded
 template <int PPL, int BMB>
-__device__ __forceinline__ bool draw_pairs_staged(uint64_t seed, const uint64_t (&path)[PPL], uint32_t step, uint32_t draw,
+__device__ __forceinline__ bool draw_pairs_staged(uint64_t seed, const uint64_t (&path)[PPL], const uint32_t (&step)[PPL], uint32_t draw,
                                                   double (&z0)[PPL], double (&z1)[PPL], const double* __restrict__ tab,
                                                   const mcx_bm_coef& C, const mcx_bm_vconst& vc)
 {
@@ -466,16 +485,16 @@ __device__ __forceinline__ bool draw_pairs_staged(uint64_t seed, const uint64_t 
     return rare;
 }
 
-// the draws of one sub-step for the PPL paths of a lane (sim_draw per path, the normals through draw_pairs_staged)
+// the draws of PPL chains (sim_draw per chain, the normals through draw_pairs_staged)
 template <int PPL, int NZ, int SIG, int BMB, class KA>
-__device__ __forceinline__ bool sim_draw_n(const KA& k, int step, const uint64_t (&path)[PPL], double (&z)[PPL][NZ], double (&u)[PPL],
+__device__ __forceinline__ bool sim_draw_n(const KA& k, const uint32_t (&step)[PPL], const uint64_t (&path)[PPL], double (&z)[PPL][NZ], double (&u)[PPL],
                                            const double* __restrict__ tab, uint64_t seed, const mcx_bm_coef& bc, const mcx_bm_vconst& vc)
 {
     bool rare = false;
 #pragma unroll
     for (int dq = 0; dq < (NZ + 1) / 2; ++dq) {
         double a[PPL], b[PPL];
-        rare |= draw_pairs_staged<PPL, BMB>(seed, path, (uint32_t)step, (uint32_t)dq, a, b, tab, bc, vc);
+        rare |= draw_pairs_staged<PPL, BMB>(seed, path, step, (uint32_t)dq, a, b, tab, bc, vc);
 #pragma unroll
         for (int q = 0; q < PPL; ++q) { z[q][2 * dq] = a[q]; if (2 * dq + 1 < NZ) z[q][2 * dq + 1] = b[q]; }
     }
@@ -484,7 +503,7 @@ __device__ __forceinline__ bool sim_draw_n(const KA& k, int step, const uint64_t
         u[q] = 0.0;
         if (sig_scheme(SIG) == MCX_SCHEME_QE || (sig_scheme(SIG) < 0 && k.n_uniform)) {
             double t0, t1;
-            draw_pair<false>(seed, path[q], (uint32_t)step, (uint32_t)((NZ + 1) / 2), u[q], t0, t1, nullptr, bc);
+            draw_pair<false>(seed, path[q], step[q], (uint32_t)((NZ + 1) / 2), u[q], t0, t1, nullptr, bc);
         }
     }
     return rare;
@@ -512,6 +531,57 @@ __device__ __forceinline__ int sim_apply(const KA& k, int step, double (&reg)[2 
     const double* __restrict__ ax = k.aux + (int64_t)step * NSLOT * MCX_AUX;
     step_slots<NSLOT, NZ, SIG, 0, POS>(k, sp, ax, reg, zc, u);
     return sp.store_idx;
+}
+
+// The wave-uniform data of one sub-step, loaded AHEAD of its draws (scalar loads issued before the Philox / Box-Muller stage):
+// the step record, the Cholesky factor and the aux rows.  Entries the compile-time model signature does not read are dead loads
+// and disappear.  Under ANALYTICAL the factor depends on the step record (one factor per distinct dt): it stays a late load.
+template <int NSLOT, int NZ>
+struct StepData {
+    mcx_step sp;
+    double L[NZ * NZ];
+    AuxRegs ax[NSLOT];
+};
+template <int NSLOT, int NZ, int SIG, class KA>
+__device__ __forceinline__ StepData<NSLOT, NZ> sim_step_load(const KA& k, int step)
+{
+    StepData<NSLOT, NZ> d;
+    d.sp = ldk_struct(&k.steps[step]);
+    constexpr bool UNIT_L00 = sig_scheme(SIG) == MCX_SCHEME_EULER || sig_scheme(SIG) == MCX_SCHEME_QE;
+    const double* __restrict__ L = UNIT_L00 ? k.chol : k.chol + (int64_t)d.sp.chol_idx * NZ * NZ;
+#pragma unroll
+    for (int q = 0; q < NZ * NZ; ++q) d.L[q] = ldk(L + q);
+    // a slot's row as three records — entries (0,1), (2,3) and the derived step constants (4..7) — so that a model reads its
+    // constants through one or two wide scalar loads (seven separate loads with their address arithmetic were a quarter of the
+    // SALU work of a sub-step); records nobody reads are dead loads
+    struct P2 { double v[2]; };
+    struct P4 { double v[4]; };
+    static_assert(MCX_AUX == 8, "aux row layout");
+    const double* __restrict__ ax = k.aux + (int64_t)step * NSLOT * MCX_AUX;
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+        const P2 a = ldk_struct((const P2*)(ax + s * MCX_AUX)), b = ldk_struct((const P2*)(ax + s * MCX_AUX + 2));
+        const P4 c = ldk_struct((const P4*)(ax + s * MCX_AUX + 4));
+        d.ax[s].v[0] = a.v[0]; d.ax[s].v[1] = a.v[1]; d.ax[s].v[2] = b.v[0]; d.ax[s].v[3] = b.v[1];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d.ax[s].v[4 + q] = c.v[q];
+    }
+    return d;
+}
+template <int NSLOT, int NZ, int SIG, bool POS = false, class KA>
+__device__ __forceinline__ int sim_apply_loaded(const KA& k, const StepData<NSLOT, NZ>& d, double (&reg)[2 * NSLOT], const double (&z)[NZ], double u)
+{
+    double zc[NZ];
+    constexpr bool UNIT_L00 = sig_scheme(SIG) == MCX_SCHEME_EULER || sig_scheme(SIG) == MCX_SCHEME_QE;
+#pragma unroll
+    for (int r = 0; r < NZ; ++r) {
+        double acc = (UNIT_L00 && r == 0) ? z[0] : d.L[r * NZ] * z[0];
+#pragma unroll
+        for (int c = 1; c <= r; ++c) acc = fma(d.L[r * NZ + c], z[c], acc);
+        zc[r] = acc;
+    }
+    step_slots<NSLOT, NZ, SIG, 0, POS>(k, d.sp, d.ax, reg, zc, u);
+    return d.sp.store_idx;
 }
 
 // one sub-step of the whole model for a lane: draws, Cholesky, per-slot maps

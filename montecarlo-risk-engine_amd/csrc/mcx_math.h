@@ -302,3 +302,32 @@ __device__ __forceinline__ double mcx_exp_tab(double x, const double* __restrict
     q *= r;                                                  // q = e^r - 1
     return ldexp(fma(T, q, T), ki >> 7);
 }
+
+// NX exponentials staged for latency: every table read goes out first, the remainder polynomials (which need no table value) cover
+// the LDS latency, then the results are assembled.  The same arithmetic as mcx_exp_tab per argument (bit-identical).
+template <int NX>
+__device__ __forceinline__ void mcx_exp_tab_n(const double (&x)[NX], double (&out)[NX], const double* __restrict__ tab, const mcx_expq_coef& C)
+{
+    double r[NX], T[NX], q[NX];
+    int ki[NX];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+        const double k = rint(x[j] * MCX_128_LN2);
+        r[j] = fma(k, -MCX_LN2_128_HI, x[j]);
+        r[j] = fma(k, -MCX_LN2_128_LO, r[j]);
+        ki[j] = (int)k;
+        T[j] = tab[ki[j] & 127];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+        double p = fma(C.c[3], r[j], C.c[2]);
+        p = fma(p, r[j], C.c[1]);
+        p = fma(p, r[j], C.c[0]);
+        p = fma(p, r[j], 1.0);
+        q[j] = p * r[j];                                       // e^r - 1
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NX; ++j) out[j] = ldexp(fma(T[j], q[j], T[j]), ki[j] >> 7);
+}
