@@ -541,6 +541,21 @@ int  mcx_select_hist_dev(mcx_handle* h, const mcx_unsecured_desc* u, const doubl
                          int32_t n_sel, const uint64_t* d_prefix, int32_t shift, int32_t bits, uint64_t* d_hist, void* stream);
 int  mcx_select_narrow(mcx_handle* h, int32_t n_dates, int32_t n_sel, const uint64_t* d_hist, int32_t shift, int32_t bits,
                        uint64_t* d_prefix, int64_t* d_rem, void* stream);
+/* Bracket pass of the select.  The six digit passes above read the exposure matrix six times; the order statistic of a date lies
+ * almost surely between two order statistics of a SAMPLE of its paths (the caller selects those on a prefix of the paths with the
+ * functions above).  mcx_select_bracket reads the matrix ONCE: d_below[m] = number of paths with exposure < d_lo[m],
+ * d_count[m] = number inside [d_lo[m], d_hi[m]], whose values are gathered into d_cand[m][0 .. min(count, cap)) in no particular
+ * order.  mcx_select_hist_rows is the digit pass over such a plain [n_rows][ld] tensor whose row m holds d_row_n[m] values
+ * (clipped to ld); the caller checks below <= rank < below + count over all GPUs and d_count <= cap, and falls back to the digit
+ * passes over the matrix for dates that fail — exactness never rests on the bracket.  A date whose candidates could not all be
+ * staged (far more paths inside the bracket than a sample suggests: every path at one value) has MCX_SELECT_LOST added to its
+ * count: count & (MCX_SELECT_LOST - 1) stays the exact number inside, the candidates are incomplete.  (metrics/pfe_metric.py:49-73) */
+#define MCX_SELECT_LOST (1ull << 44)
+int  mcx_select_bracket(mcx_handle* h, const mcx_unsecured_desc* u, const double* d_expo_ns, int64_t n_paths, int64_t ld,
+                        const double* d_lo, const double* d_hi, uint64_t* d_below, uint64_t* d_count, double* d_cand, int64_t cap,
+                        void* stream);
+int  mcx_select_hist_rows(mcx_handle* h, const double* d_rows, int32_t n_rows, int64_t ld, const uint64_t* d_row_n,
+                          int32_t n_sel, const uint64_t* d_prefix, int32_t shift, int32_t bits, uint64_t* d_hist, void* stream);
 
 /* Multi-GPU exchange (paths shard over the GPUs of a node, one process per GPU; the only data that crosses
  * GPUs are accumulator records, LSM moments and select histograms).  RCCL over xGMI, loaded at run time (librccl.so.1 — the

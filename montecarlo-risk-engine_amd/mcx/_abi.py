@@ -6,6 +6,7 @@ import ctypes as C
 import numpy as np
 
 ABI_VERSION = 5
+SELECT_LOST = 1 << 44        # MCX_SELECT_LOST (mcx_select_bracket)
 MAX_SLOTS = 8
 MAX_Z = 8
 MAX_STATE = 16

@@ -26,7 +26,7 @@ _EXPORTS = [
     "mcx_fused_is_straight_line", "mcx_tangent_paths", "mcx_tangent_lsm", "mcx_tangent_eval", "mcx_tangent_cva", "mcx_tangent_profiles", "mcx_tangent_pick",
     "mcx_box_muller", "mcx_tangent_european", "mcx_fused_create", "mcx_fused_destroy", "mcx_fused_num_records", "mcx_fused_run", "mcx_fused_eval_paths", "mcx_fused_run_device", "mcx_fused_eval_paths_device", "mcx_fused_set_timing", "mcx_fused_kernel_times",
     "mcx_value_poly_fit", "mcx_book_collapse_values", "mcx_book_value_poly_info", "mcx_rows_minmax",
-    "mcx_reduce_vector", "mcx_reduce_profiles", "mcx_reduce_cva", "mcx_unsecured", "mcx_select_hist", "mcx_select_hist_dev", "mcx_select_narrow",
+    "mcx_reduce_vector", "mcx_reduce_profiles", "mcx_reduce_cva", "mcx_unsecured", "mcx_select_hist", "mcx_select_hist_dev", "mcx_select_narrow", "mcx_select_bracket", "mcx_select_hist_rows",
 ]
 
 
@@ -557,12 +557,33 @@ class HipBackend:
 
 
     # device-resident select (no host round trip per digit pass)
-    def select_hist_dev(self, unsec, expo_ns: torch.Tensor, n_sel: int, prefix: torch.Tensor, shift: int, bits: int, out: torch.Tensor):
-        n = expo_ns.shape[1]
+    def select_hist_dev(self, unsec, expo_ns: torch.Tensor, n_sel: int, prefix: torch.Tensor, shift: int, bits: int, out: torch.Tensor,
+                        n_paths: int | None = None):
+        """n_paths < expo_ns.shape[1]: the pass over a prefix of the paths (the sample of the bracket select)"""
+        ld = expo_ns.shape[1]
+        n = ld if n_paths is None else min(int(n_paths), ld)
         unsec.desc.n_rows = expo_ns.shape[0]
-        self._check(self.lib.mcx_select_hist_dev(self.h, C.byref(unsec.desc), _vp(expo_ns.data_ptr()), C.c_int64(n), C.c_int64(n),
+        self._check(self.lib.mcx_select_hist_dev(self.h, C.byref(unsec.desc), _vp(expo_ns.data_ptr()), C.c_int64(n), C.c_int64(ld),
                                                  C.c_int32(n_sel), _vp(prefix.data_ptr()), C.c_int32(shift), C.c_int32(bits),
                                                  _vp(out.data_ptr()), self._stream()), "mcx_select_hist_dev")
+        return out
+
+    def select_bracket(self, unsec, expo_ns: torch.Tensor, lo: torch.Tensor, hi: torch.Tensor, counts: torch.Tensor, cand: torch.Tensor):
+        """one pass over the exposures: counts[0][m] = paths below lo[m], counts[1][m] = paths inside [lo[m], hi[m]], gathered into
+        cand[m] (mcx_select_bracket); counts is an int64 [2][n_dates] device tensor, cand float64 [n_dates][cap]"""
+        n = expo_ns.shape[1]
+        unsec.desc.n_rows = expo_ns.shape[0]
+        assert counts.dtype == torch.int64 and counts.shape == (2, unsec.n_dates) and counts.is_contiguous() and cand.is_contiguous()
+        self._check(self.lib.mcx_select_bracket(self.h, C.byref(unsec.desc), _vp(expo_ns.data_ptr()), C.c_int64(n), C.c_int64(n),
+                                                _vp(lo.data_ptr()), _vp(hi.data_ptr()), _vp(counts[0].data_ptr()), _vp(counts[1].data_ptr()),
+                                                _vp(cand.data_ptr()), C.c_int64(cand.shape[1]), self._stream()), "mcx_select_bracket")
+
+    def select_hist_rows(self, rows: torch.Tensor, row_n: torch.Tensor, n_sel: int, prefix: torch.Tensor, shift: int, bits: int, out: torch.Tensor):
+        """digit pass over a plain [n_rows][ld] tensor whose row m holds row_n[m] values (mcx_select_hist_rows)"""
+        assert rows.is_contiguous() and row_n.dtype == torch.int64
+        self._check(self.lib.mcx_select_hist_rows(self.h, _vp(rows.data_ptr()), C.c_int32(rows.shape[0]), C.c_int64(rows.shape[1]),
+                                                  _vp(row_n.data_ptr()), C.c_int32(n_sel), _vp(prefix.data_ptr()), C.c_int32(shift),
+                                                  C.c_int32(bits), _vp(out.data_ptr()), self._stream()), "mcx_select_hist_rows")
         return out
 
     def select_narrow(self, hist: torch.Tensor, n_dates: int, n_sel: int, shift: int, bits: int, prefix: torch.Tensor, rem: torch.Tensor):

@@ -113,6 +113,8 @@ class SimulationController:
         self.collapse_values = True
         self.collapse_pad, self.collapse_rel_tol, self.collapse_min_terms = 0.3, 1e-14, 6
         self.n_collapsed_events = 0
+        # PFE order statistics: one bracket pass over the exposure matrix + digit passes on the gathered candidates (csrc/k5_select.hip)
+        self.bracket_select, self.bracket_sample = True, 16384
         self._backend = backend
         for i, p in enumerate(products):
             p.product_id = i
@@ -624,22 +626,35 @@ class SimulationController:
         n = 1 if metric.metric_type in {MetricType.PV, MetricType.CVA, MetricType.EEPE} else len(self.metric_exposure_timeline)
         return [(0.0, 0.0) for _ in range(n)]
 
+    def _radix_select(self, shard: Shard, E: int, n_sel: int, rem, hist_pass, digits=_SELECT_DIGITS, keys=False) -> np.ndarray:
+        """the six digit passes of an exact select, enqueued back to back: histogram (hist_pass), all-reduce over the ranks
+        (stream-ordered), bin selection on the device; ONE copy of the final keys (a host round trip per pass is six stalls of the
+        stream).  rem: int64 [E][n_sel] device tensor of ranks (consumed).  shard None: a rank-local select, no collective.
+        digits: a leading subset of the passes leaves the low bits of the keys zero (keys=True returns the uint64 keys)."""
+        be = self.backend
+        prefix = be.zeros(E, n_sel, dtype=torch.int64)
+        buf = self._buffer_typed("select_hist", torch.int64, E * n_sel * (1 << max(b for _, b in _SELECT_DIGITS)))
+        for shift, bits in digits:
+            hist = buf[:E * n_sel * (1 << bits)].view(E, n_sel, 1 << bits)
+            hist_pass(prefix, shift, bits, hist)
+            if shard is not None:
+                shard.all_reduce_(hist)
+            be.select_narrow(hist, E, n_sel, shift, bits, prefix, rem)
+        k = prefix.cpu().numpy().view(np.uint64)
+        return k if keys else _key_to_double(k)
+
     def _select_order_stats(self, shard: Shard, unsec: UnsecuredSpec, expo_ns, ranks: list[int]) -> np.ndarray:
         """exact global order statistics x_(r) for r in ranks at every metric date -> [n_dates][len(ranks)]"""
         be = self.backend
         E, n_sel = unsec.n_dates, len(ranks)
         if hasattr(be, "select_narrow"):
-            # the six digit passes enqueued back to back: histogram, all-reduce over the ranks (stream-ordered), bin selection on
-            # the device; ONE copy of the final keys (a host round trip per pass is six stalls of the stream)
-            prefix = be.zeros(E, n_sel, dtype=torch.int64)
+            if hasattr(be, "select_bracket") and self.bracket_select:
+                out = self._select_with_bracket(shard, unsec, expo_ns, ranks)
+                if out is not None:
+                    return out
             rem = be.from_numpy(np.tile(np.asarray(ranks, dtype=np.int64), (E, 1)))
-            buf = self._buffer_typed("select_hist", torch.int64, E * n_sel * (1 << max(b for _, b in _SELECT_DIGITS)))
-            for shift, bits in _SELECT_DIGITS:
-                hist = buf[:E * n_sel * (1 << bits)].view(E, n_sel, 1 << bits)
-                be.select_hist_dev(unsec, expo_ns, n_sel, prefix, shift, bits, hist)
-                shard.all_reduce_(hist)
-                be.select_narrow(hist, E, n_sel, shift, bits, prefix, rem)
-            return _key_to_double(prefix.cpu().numpy().view(np.uint64))
+            return self._radix_select(shard, E, n_sel, rem, lambda prefix, shift, bits, hist:
+                                      be.select_hist_dev(unsec, expo_ns, n_sel, prefix, shift, bits, hist))
         prefix = np.zeros((E, n_sel), dtype=np.uint64)
         rem = np.tile(np.asarray(ranks, dtype=np.int64), (E, 1))
         for shift, bits in _SELECT_DIGITS:
@@ -651,6 +666,74 @@ class SimulationController:
             rem = rem - below
             prefix = prefix | (b.astype(np.uint64) << np.uint64(shift))
         return _key_to_double(prefix)
+
+    def _select_with_bracket(self, shard: Shard, unsec: UnsecuredSpec, expo_ns, ranks: list[int]):
+        """The select in ONE pass over the exposure matrix instead of six (pfe_metric.py:49-73 sorts it).  Per date the wanted order
+        statistics lie, almost surely, between two order statistics of a sample of the paths: (1) exact select of the bracket
+        ends on the first `bracket_sample` local paths (paths are exchangeable; the widest bracket over the ranks is taken);
+        (2) mcx_select_bracket counts the paths below the bracket and gathers the ~1-2 % inside it; (3) the digit passes run on the
+        gathered candidates.  Exactness never rests on the bracket: a date whose ranks are not inside it (checked on the global
+        counts) or whose candidates overflowed their buffer — every path at one value, say — is redone by the digit passes over
+        the matrix.  None: too few paths for the detour to pay."""
+        be = self.backend
+        E, n_sel = unsec.n_dates, len(ranks)
+        n_local, n_tot = int(expo_ns.shape[1]), int(self.num_paths_mainsim)
+        S = min(n_local, int(self.bracket_sample))
+        if n_tot < 32 * self.bracket_sample or S < 4096:
+            return None
+        r_min, r_max = min(ranks), max(ranks)
+        p = 0.5 * (r_min + r_max) / n_tot
+        sig = math.sqrt(S * max(p * (1.0 - p), 1.0 / S))
+        s_lo, s_hi = int(math.floor(r_min / n_tot * S - 5.0 * sig - 2)), int(math.ceil(r_max / n_tot * S + 5.0 * sig + 2))
+        open_lo, open_hi = s_lo < 0, s_hi > S - 1
+        s_rk = [min(max(s_lo, 0), S - 1), min(max(s_hi, 0), S - 1)]
+        rem_s = be.from_numpy(np.tile(np.asarray(s_rk, dtype=np.int64), (E, 1)))
+        # (exact order statistics of the sample: a date on which the sampled paths share one exposure then gives lo == hi)
+        ends = self._radix_select(None, E, 2, rem_s, lambda prefix, shift, bits, hist:
+                                  be.select_hist_dev(unsec, expo_ns, 2, prefix, shift, bits, hist, n_paths=S)).copy()
+        if open_lo:
+            ends[:, 0] = -np.inf
+        if open_hi:
+            ends[:, 1] = np.inf
+        g = shard.all_gather_np(ends)                                      # [world][E][2]: every rank sampled its own paths
+        lo, hi = g[:, :, 0].min(axis=0), g[:, :, 1].max(axis=0)
+        width = (s_rk[1] - s_rk[0] + 1) / S                                # expected share of the paths inside the bracket
+        cap = int(min(n_local, max(8192, 4.0 * width * n_local)))
+        cap = (cap + 1023) // 1024 * 1024
+        cand = self._buffer("select_cand", E, cap)
+        counts = self._buffer_typed("select_counts", torch.int64, 2 * E)[:2 * E].view(2, E)
+        be.select_bracket(unsec, expo_ns, be.from_numpy(lo), be.from_numpy(hi), counts, cand)
+        local_n = counts[1].clone()                                          # candidates this rank holds (before the sum over ranks)
+        shard.all_reduce_(counts)
+        cnt = counts.cpu().numpy()
+        lost_bit = np.int64(_abi.SELECT_LOST)
+        below, inside = cnt[0], cnt[1] & (lost_bit - 1)
+        local_cnt = local_n.cpu().numpy() & (lost_bit - 1)
+        # some rank's candidate row overflowed, or some wave could not stage all its candidates (MCX_SELECT_LOST)
+        over = (shard.all_reduce_np((local_cnt > cap).astype(np.float64)) > 0) | (cnt[1] >= lost_bit)
+        contained = (below <= r_min) & (r_max < below + inside)
+        # a bracket that is one point (every sampled path at one exposure: before the first date, after the last exercise, the
+        # threshold's atom at zero): everything inside it IS that value, the candidates are not needed
+        point = contained & (lo == hi)
+        ok = contained & ~over & ~point
+        out = np.zeros((E, n_sel))
+        out[point] = lo[point][:, None]
+        if ok.any():
+            rem = np.asarray(ranks, dtype=np.int64)[None, :] - below[:, None]
+            rem[~ok] = 0
+            row_n = be.from_numpy(np.where(ok, np.minimum(local_cnt, cap), 0).astype(np.int64))
+            vals = self._radix_select(shard, E, n_sel, be.from_numpy(rem), lambda prefix, shift, bits, hist:
+                                      be.select_hist_rows(cand, row_n, n_sel, prefix, shift, bits, hist))
+            out[ok] = vals[ok]
+        bad = np.nonzero(~ok & ~point)[0]
+        if len(bad):
+            sub = UnsecuredSpec(unsec.rows[bad], None if unsec.delayed is None else unsec.delayed[bad], float(unsec.desc.threshold),
+                                bool(unsec.desc.collateralized))
+            rem_b = be.from_numpy(np.tile(np.asarray(ranks, dtype=np.int64), (len(bad), 1)))
+            out[bad] = self._radix_select(shard, len(bad), n_sel, rem_b, lambda prefix, shift, bits, hist:
+                                          be.select_hist_dev(sub, expo_ns, n_sel, prefix, shift, bits, hist))
+        self.last_select = dict(bracket_dates=int(ok.sum()), point_dates=int(point.sum()), fallback_dates=int(len(bad)), cap=cap, sample=S)
+        return out
 
     def _evaluate_netting_set(self, shard: Shard, ns_i: int, ns: NettingSet, cfs, expo, paths, has_pathwise: bool,
                               analytical_acc: list[float], fr: dict | None = None):

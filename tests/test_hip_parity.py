@@ -5,6 +5,7 @@
  2. Philox: same seeds/counters on GPU and CPU oracle -> paths agree to <= 1e-11 relative (libm ulp differences only),
     metrics to <= 1e-9; plus RNG known-answer vectors.
  3. kernels against each other: MFMA vs VALU normal equations, radix select vs sort."""
+import math
 import os
 import sys
 
@@ -219,6 +220,41 @@ def test_radix_select_matches_sort(hip, oracle):
     q = 19000
     vals = sc._select_order_stats(Shard(), unsec, hip.from_numpy(x), [q - 1, q, q + 1])
     ref = oracle.pfe_sort(unsec, torch.from_numpy(x), q)
+    assert np.array_equal(vals, ref)
+
+
+@pytest.mark.parametrize("quantile", [0.95, 0.5, 0.999, 0.0005])
+def test_bracket_select_matches_sort_and_the_digit_passes(quantile, hip):
+    """PFE order statistics through ONE bracket pass + candidates (k5_bracket) against torch.sort and against the six digit passes:
+    smooth rows, heavy ties, a flat row (every candidate buffer overflows: per-date fall-back), a row whose mass sits in two far
+    clusters (the sample bracket may miss: per-date fall-back), threshold applied (netting_set.py:156-184)"""
+    from mcx.plan import UnsecuredSpec
+    from mcx.parallel import Shard
+    rng = np.random.default_rng(11)
+    n, E = 1 << 20, 6
+    x = rng.standard_normal((E, n))
+    x[1] = np.round(x[1], 2)                                   # heavy ties
+    x[2] = 0.25                                                # flat
+    x[3] = np.where(rng.random(n) < quantile, -1e3 + x[3], 1e3 + x[3])      # the wanted rank sits at the jump between two clusters
+    x[4] = np.exp(3.0 * x[4])                                  # heavy right tail
+    x[5, : n // 3] = 0.0                                       # an atom at zero (exposures of paths that exercised)
+    unsec = UnsecuredSpec(np.arange(E), None, 0.1, False)
+    sc, _ = cases.make_controller("bs_european", hip, inject=False)
+    sc.num_paths_mainsim = n
+    xt = hip.from_numpy(x)
+    q = min(max(int(math.ceil(quantile * n)) - 1, 1), n - 2)
+    ranks = [q - 1, q, q + 1]
+    vals = sc._select_order_stats(Shard(), unsec, xt, ranks)
+    info = sc.last_select
+    # (at q = 0.5 the threshold's atom at zero holds the median of three rows: their candidates overflow and they fall back too)
+    assert info["bracket_dates"] >= (3 if quantile > 0.9 else 1)
+    assert info["point_dates"] >= 1 or not (0.01 < quantile < 0.99)        # the flat row (an open-ended bracket is not a point: it falls back)
+    assert info["bracket_dates"] + info["point_dates"] + info["fallback_dates"] == E
+    sc.bracket_select = False
+    digits = sc._select_order_stats(Shard(), unsec, xt, ranks)
+    u = torch.where(xt > 0.1, xt - 0.1, torch.where(xt < -0.1, xt + 0.1, torch.zeros_like(xt)))     # dev_thr
+    ref = torch.sort(u, dim=1).values[:, ranks].cpu().numpy()
+    assert np.array_equal(vals, digits)
     assert np.array_equal(vals, ref)
 
 
