@@ -39,7 +39,10 @@ struct KTArgs {
 };
 
 // Black-Scholes: params [spot, sigma, rate], state S
-template <bool INJECT>
+// NNS: netting sets with accumulators (1 for a single-netting-set book: the BASELINE configs; MCX_FUSED_MAX_NS otherwise).  The
+// payoff block is force-inlined at its two call sites: left as an out-of-line lambda it took the accumulator arrays by address
+// and the backend kept them in scratch memory (48 B per lane here, 240 B in kt_heston).
+template <bool INJECT, int NNS>
 __global__ __launch_bounds__(MCX_BLOCK) void kt_bs(const KTArgs a)
 {
     constexpr int P = 3;
@@ -52,8 +55,12 @@ __global__ __launch_bounds__(MCX_BLOCK) void kt_bs(const KTArgs a)
     const double* p = k.slots[0].p;
     const Dual<P> sigma = dseed<P>(p[1], 1), rate = dseed<P>(p[2], 2);
     Dual<P> S = dseed<P>(p[0], 0);
-    double acc[MCX_FUSED_MAX_NS] = {0, 0, 0, 0}, dacc[MCX_FUSED_MAX_NS][P] = {};
-    auto on_date = [&](int t) {
+    double acc[NNS], dacc[NNS][P];
+#pragma unroll
+    for (int n = 0; n < NNS; ++n) { acc[n] = 0.0;
+#pragma unroll
+        for (int j = 0; j < P; ++j) dacc[n][j] = 0.0; }
+    auto on_date = [&](int t) __attribute__((always_inline)) {
         for (int q = 0; q < a.n_opts; ++q) {
             const mcx_tangent_option o = ldk_struct(&a.opts[q]);
             if (o.t_idx != t) continue;
@@ -63,12 +70,12 @@ __global__ __launch_bounds__(MCX_BLOCK) void kt_bs(const KTArgs a)
             const double pay = fmax(x, 0.0);
             const double inv = 1.0 / o.numeraire;
 #pragma unroll
-            for (int n = 0; n < MCX_FUSED_MAX_NS; ++n) {
-                if (n != o.netting_set) continue;
-                acc[n] += pay * inv;
+            for (int n = 0; n < NNS; ++n) {
+                const double sel = (NNS == 1 || n == o.netting_set) ? inv : 0.0;        // (a select, not a branch: static register indices)
+                acc[n] += pay * sel;
 #pragma unroll
-                for (int j = 0; j < P; ++j) dacc[n][j] += w * o.sign * S.d[j] * inv;
-                dacc[n][2] -= pay * inv * inv * o.dnum_drate;
+                for (int j = 0; j < P; ++j) dacc[n][j] += w * o.sign * S.d[j] * sel;
+                dacc[n][2] -= pay * sel * inv * o.dnum_drate;
             }
         }
     };
@@ -90,11 +97,12 @@ __global__ __launch_bounds__(MCX_BLOCK) void kt_bs(const KTArgs a)
         if (sp.store_idx >= 0) on_date(sp.store_idx);
     }
 #pragma unroll
-    for (int n = 0; n < MCX_FUSED_MAX_NS; ++n) {          // compile-time indices: the accumulators stay in registers
-        if (n >= a.n_ns) break;
-        a.cfs[(int64_t)n * a.ld_out + i] = acc[n];
+    for (int n = 0; n < NNS; ++n) {          // compile-time indices: the accumulators stay in registers
+        if (n < a.n_ns) {
+            a.cfs[(int64_t)n * a.ld_out + i] = acc[n];
 #pragma unroll
-        for (int j = 0; j < P; ++j) a.dcfs[((int64_t)n * P + j) * a.ld_out + i] = dacc[n][j];
+            for (int j = 0; j < P; ++j) a.dcfs[((int64_t)n * P + j) * a.ld_out + i] = dacc[n][j];
+        }
     }
 }
 
@@ -116,7 +124,7 @@ __device__ __forceinline__ Dual<PB> dext(const Dual<PA>& a)
     return r;
 }
 
-template <bool INJECT, bool QE>
+template <bool INJECT, bool QE, int NNS>
 __global__ __launch_bounds__(MCX_BLOCK) void kt_heston(const KTArgs a)
 {
     constexpr int P = 7, PV = QE ? 4 : 5, PL = 5;
@@ -135,8 +143,12 @@ __global__ __launch_bounds__(MCX_BLOCK) void kt_heston(const KTArgs a)
     Dual<PV> v = dseed<PV>(p[6], 3);
     double elapsed = 0.0;                                              // d logS / d rate
     const bool fuzzy = ((k.flags | k.slots[0].flags) & MCX_FLAG_SMOOTHING) != 0;
-    double acc[MCX_FUSED_MAX_NS] = {0, 0, 0, 0}, dacc[MCX_FUSED_MAX_NS][P] = {};
-    auto on_date = [&](int t) {
+    double acc[NNS], dacc[NNS][P];
+#pragma unroll
+    for (int n = 0; n < NNS; ++n) { acc[n] = 0.0;
+#pragma unroll
+        for (int j = 0; j < P; ++j) dacc[n][j] = 0.0; }
+    auto on_date = [&](int t) __attribute__((always_inline)) {
         for (int q = 0; q < a.n_opts; ++q) {
             const mcx_tangent_option o = ldk_struct(&a.opts[q]);
             if (o.t_idx != t) continue;
@@ -148,12 +160,12 @@ __global__ __launch_bounds__(MCX_BLOCK) void kt_heston(const KTArgs a)
             const double pay = fmax(x, 0.0);
             const double inv = 1.0 / o.numeraire;
 #pragma unroll
-            for (int n = 0; n < MCX_FUSED_MAX_NS; ++n) {
-                if (n != o.netting_set) continue;
-                acc[n] += pay * inv;
+            for (int n = 0; n < NNS; ++n) {
+                const double sel = (NNS == 1 || n == o.netting_set) ? inv : 0.0;        // (a select, not a branch: static register indices)
+                acc[n] += pay * sel;
 #pragma unroll
-                for (int j = 0; j < P; ++j) dacc[n][j] += w * o.sign * dS[j] * inv;
-                dacc[n][2] -= pay * inv * inv * o.dnum_drate;
+                for (int j = 0; j < P; ++j) dacc[n][j] += w * o.sign * dS[j] * sel;
+                dacc[n][2] -= pay * sel * inv * o.dnum_drate;
             }
         }
     };
@@ -213,11 +225,12 @@ __global__ __launch_bounds__(MCX_BLOCK) void kt_heston(const KTArgs a)
         if (sp.store_idx >= 0) on_date(sp.store_idx);
     }
 #pragma unroll
-    for (int n = 0; n < MCX_FUSED_MAX_NS; ++n) {          // compile-time indices: the accumulators stay in registers
-        if (n >= a.n_ns) break;
-        a.cfs[(int64_t)n * a.ld_out + i] = acc[n];
+    for (int n = 0; n < NNS; ++n) {          // compile-time indices: the accumulators stay in registers
+        if (n < a.n_ns) {
+            a.cfs[(int64_t)n * a.ld_out + i] = acc[n];
 #pragma unroll
-        for (int j = 0; j < P; ++j) a.dcfs[((int64_t)n * P + j) * a.ld_out + i] = dacc[n][j];
+            for (int j = 0; j < P; ++j) a.dcfs[((int64_t)n * P + j) * a.ld_out + i] = dacc[n][j];
+        }
     }
 }
 
@@ -299,16 +312,20 @@ extern "C" int mcx_tangent_european(mcx_handle* h, const mcx_sim* sim, const mcx
     }
     const int grid = (int)((n_paths + MCX_BLOCK - 1) / MCX_BLOCK);
     const bool inj = d_inject_z != nullptr;
+    const bool one = n_netting_sets == 1;
+#define MCX_KT(kern_one, kern_all) do { if (one) hipLaunchKernelGGL(kern_one, dim3(grid), dim3(MCX_BLOCK), 0, s, a); \
+                                        else hipLaunchKernelGGL(kern_all, dim3(grid), dim3(MCX_BLOCK), 0, s, a); } while (0)
     if (d.slots[0].kind == MCX_MODEL_BS) {
-        if (inj) hipLaunchKernelGGL(kt_bs<true>, dim3(grid), dim3(MCX_BLOCK), 0, s, a);
-        else hipLaunchKernelGGL(kt_bs<false>, dim3(grid), dim3(MCX_BLOCK), 0, s, a);
+        if (inj) MCX_KT((kt_bs<true, 1>), (kt_bs<true, MCX_FUSED_MAX_NS>));
+        else MCX_KT((kt_bs<false, 1>), (kt_bs<false, MCX_FUSED_MAX_NS>));
     } else {
         const bool qe = d.scheme == MCX_SCHEME_QE;
-        if (qe && inj) hipLaunchKernelGGL((kt_heston<true, true>), dim3(grid), dim3(MCX_BLOCK), 0, s, a);
-        else if (qe) hipLaunchKernelGGL((kt_heston<false, true>), dim3(grid), dim3(MCX_BLOCK), 0, s, a);
-        else if (inj) hipLaunchKernelGGL((kt_heston<true, false>), dim3(grid), dim3(MCX_BLOCK), 0, s, a);
-        else hipLaunchKernelGGL((kt_heston<false, false>), dim3(grid), dim3(MCX_BLOCK), 0, s, a);
+        if (qe && inj) MCX_KT((kt_heston<true, true, 1>), (kt_heston<true, true, MCX_FUSED_MAX_NS>));
+        else if (qe) MCX_KT((kt_heston<false, true, 1>), (kt_heston<false, true, MCX_FUSED_MAX_NS>));
+        else if (inj) MCX_KT((kt_heston<true, false, 1>), (kt_heston<true, false, MCX_FUSED_MAX_NS>));
+        else MCX_KT((kt_heston<false, false, 1>), (kt_heston<false, false, MCX_FUSED_MAX_NS>));
     }
+#undef MCX_KT
     MCX_HIP(h, hipGetLastError());
     return 0;          // stream-ordered (descriptors travel through the handle's staging ring)
 }

@@ -130,3 +130,33 @@ def test_pipelined_passes_gather_the_records_of_every_emulated_rank(hip):
         assert len(vals) == 4
         for v, e in vals:
             assert np.isclose(v, ref[0], rtol=1e-10) and np.isclose(e, ref[1], rtol=1e-6)
+
+
+@pytest.mark.gpu
+def test_bracket_select_over_three_emulated_ranks(hip):
+    """PFE through the one-pass bracket select (k5_bracket) with the paths on three ranks: every rank samples its own paths, the
+    widest bracket is taken, `below` / `inside` counts and the candidates' digit histograms are all-reduced — the order statistics
+    must equal the single-shard ones exactly given equal exposures (here: to the last bits of the regression coefficients)"""
+    from mcx import _native
+    n_main, n_pre = 600001, 20003
+
+    def build(be):
+        sc, _ = cases.make_controller("bermudan_swaption", be, inject=False)
+        sc.materialize = False
+        sc.num_paths_mainsim, sc.num_paths_presim = n_main, n_pre
+        return sc
+
+    single = build(hip)
+    ref = _results(single.run_simulation())
+    assert single.last_select["bracket_dates"] > 0
+
+    def body(sc, rank):
+        res = sc.run_simulation()
+        return _results(res), dict(sc.last_select)
+
+    out, calls = run_ranks(3, lambda rank: build(_native.HipBackend(0)), body)
+    for got, info in out:
+        assert info["bracket_dates"] > 0
+        for ns_r, ns_g in zip(ref, got):
+            for m_r, m_g in zip(ns_r, ns_g):
+                assert np.allclose(m_r[:, 0], m_g[:, 0], rtol=1e-9, atol=1e-12)
