@@ -18,6 +18,8 @@ ORC_LIB = os.path.join(ORC_DIR, "liborc.so")
 
 
 def build_oracle():
+    if os.environ.get("MCX_ORACLE_LIB"):                 # the sanitizer build of the checker (oracle/Makefile, SAN=1)
+        return os.path.abspath(os.environ["MCX_ORACLE_LIB"])
     src = os.path.join(ORC_DIR, "mcx_oracle.c")
     if not os.path.exists(ORC_LIB) or os.path.getmtime(ORC_LIB) < max(os.path.getmtime(src),
                                                                       os.path.getmtime(os.path.join(ROOT, "include", "mcx.h"))):

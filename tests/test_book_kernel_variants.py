@@ -21,6 +21,10 @@ pytestmark = pytest.mark.gpu
 
 LIGHT = (1 << 20) + 333          # >= 4096 blocks: k2_eval_book_v<4, .> and k4_cva_paths_v<2>
 WIDE = (1 << 19) + 333           # >= 2048 blocks: k2_eval_book_v<2, .>
+# books with a hard indicator in front of the compared tensors: the exercise decision `immediate > continuation` of Bermudan /
+# American / FlexiCall products (bermudan_option.py:93-131) may flip on a last-bit difference of the regression coefficients for
+# a vanishing fraction of paths; every other book's cashflows and exposures must agree entry by entry
+FLIP_BOOKS = {"bermudan_swaption", "american_put", "flexicall"}
 BOOKS = [("irs_cva", LIGHT), ("bond_option", LIGHT), ("netting", WIDE), ("mixed_cva", WIDE), ("bermudan_swaption", WIDE),
          ("american_put", WIDE), ("flexicall", WIDE), ("basket_multi", WIDE), ("binary_asian", WIDE), ("bs_european_exposure", WIDE)]
 
@@ -45,9 +49,8 @@ def test_multi_path_book_kernels_match_oracle(name, n_main, hip, oracle):
             assert b is None
             continue
         a, b = a.cpu().numpy(), b.numpy()
-        # exercise / fuzzy indicators can flip on a 1-ulp difference of the regression coefficients for a vanishing fraction of paths
         bad = ~np.isclose(a, b, rtol=1e-9, atol=1e-11)
-        assert bad.mean() < 1e-4, (name, key, bad.mean(), np.abs(a - b).max())
+        assert bad.mean() <= (1e-4 if name in FLIP_BOOKS else 0.0), (name, key, bad.mean(), np.abs(a - b).max())
     for ns_i in range(len(sg.netting_sets)):
         for m_i, metric in enumerate(sg.risk_metrics.metrics):
             x = np.array(rg.results[ns_i][m_i], dtype=np.float64)

@@ -80,12 +80,12 @@ def test_rerun_reuses_the_compiled_book_and_recompiles_after_a_parameter_change(
     assert not np.allclose(np.array(r3.results[0][0])[:, 0], np.array(r1.results[0][0])[:, 0], rtol=1e-9)
 
 
-def test_monte_carlo_second_order_derivatives_converge_to_the_black_scholes_hessian(oracle):
+def _second_order_check(backend, n_paths):
     """compute_higher_derivatives() on a Monte-Carlo PV (controller.py:253-255, 631-648): differences of the pathwise first-order
-    sensitivities with common random numbers; 200 k paths against the closed-form gamma / vomma / vanna (Monte-Carlo noise ~2 %)"""
+    sensitivities with common random numbers against the closed-form gamma / vomma / vanna (Monte-Carlo noise ~2 % at 200 k paths)"""
     from scipy.stats import norm
     ns, model, rm = cases.bs_european()
-    sc = SimulationController(ns, model, rm, 200000, 0, 2, cases.A, differentiate=True, backend=oracle)
+    sc = SimulationController(ns, model, rm, n_paths, 0, 2, cases.A, differentiate=True, backend=backend)
     sc.compute_higher_derivatives()
     res = sc.run_simulation()
     H = res.get_second_derivatives(0, "pv", evaluation_idx=0)
@@ -99,6 +99,22 @@ def test_monte_carlo_second_order_derivatives_converge_to_the_black_scholes_hess
     assert abs(H["spot"]["volatility"] - (-norm.pdf(d1) * d2 / sig)) < 0.08 * abs(norm.pdf(d1) * d2 / sig)
     assert abs(H["spot"]["volatility"] - H["volatility"]["spot"]) < 0.08 * abs(H["spot"]["volatility"])          # symmetric up to noise
     assert res.get_derivatives(0, "pv", evaluation_idx=0)["spot"] == pytest.approx(0.875, abs=0.01)
+    return H
+
+
+def test_monte_carlo_second_order_derivatives_converge_to_the_black_scholes_hessian(oracle):
+    _second_order_check(oracle, 200000)
+
+
+@pytest.mark.gpu
+def test_monte_carlo_second_order_derivatives_on_the_gpu(hip, oracle):
+    """the same through the tangent kernel on the GPU (kt_bs: 2P + 1 first-order passes), and equal to the oracle's Hessian on the
+    same Philox counters"""
+    Hg = _second_order_check(hip, 200000)
+    Ho = _second_order_check(oracle, 200000)
+    for a in Hg:
+        for b in Hg[a]:
+            assert Hg[a][b] == pytest.approx(Ho[a][b], rel=1e-6, abs=1e-9), (a, b)
 
 
 @pytest.mark.gpu

@@ -21,6 +21,7 @@ if ROOT not in sys.path:
 
 pytestmark = pytest.mark.gpu
 NON_AAD = [n for n, c in cases.CASES.items() if not c[5]]
+PATH_FLIP_CASES = {"heston_qe", "heston_highpsi_qe"}          # hard (unsmoothed) QE branch indicators inside the path map
 
 
 def _check_against_golden(sc, res, g, name):
@@ -68,9 +69,12 @@ def test_philox_gpu_vs_oracle(name, fused, hip, oracle):
     rg, rc = sc_g.run_simulation(), sc_c.run_simulation()
     pg = sc_g.last_state["paths"].cpu().numpy()
     pc = sc_c.last_state["paths"].numpy()
-    # hard QE / exercise indicators can flip on a 1-ulp difference for a vanishing fraction of paths: compare robustly
+    # Only a HARD indicator inside the step map can make a path differ beyond rounding: the two branch tests of the Heston QE
+    # step without smoothing (heston.py:214-240) may flip on a 1-ulp difference of psi or u for a vanishing fraction of paths.
+    # Every other model's paths (and exercise decisions never touch the paths) must agree entry by entry.
     bad = ~np.isclose(pg, pc, rtol=1e-10, atol=1e-12)
-    assert bad.mean() < 1e-4, bad.mean()
+    allowed = 1e-4 if name in PATH_FLIP_CASES else 0.0
+    assert bad.mean() <= allowed, (name, bad.mean())
     for ns_i in range(len(sc_g.netting_sets)):
         for m_i, metric in enumerate(sc_g.risk_metrics.metrics):
             a = np.array(rg.results[ns_i][m_i], dtype=np.float64)
