@@ -360,7 +360,7 @@ def run_with_tangent_book(sc):
     n_ns, n_metrics = len(sc.netting_sets), len(rm.metrics)
     n_eval = [len(res0.results[0][m_i]) for m_i in range(n_metrics)]
     grads = [[[[0.0] * P for _ in range(n_eval[m_i])] for m_i in range(n_metrics)] for _ in range(n_ns)]     # [ns][metric][eval][param]
-    jobs = [(p_i, p) for p_i, p in enumerate(sc.products) if base._product_requires_regression(p) and p_i in base._mc_products]
+    jobs = [(p_i, p) for p_i, p in enumerate(sc.products) if p_i in base._mc_set and base._product_requires_regression(p)]
     rows = base.metric_exposure_indices.numpy().astype(np.int32) if rm.requires_exposure_profiles() else np.zeros(0, dtype=np.int32)
 
     def mean_of(vec):

@@ -223,6 +223,7 @@ class SimulationController:
         self._expo_coeff_base, self._reg_coeff_base, self._cash_meta = [], [], []
         self._extra_coeff_base = []
         self._mc_products = []
+        self._mc_set = set()
         off = 0
         for p_i, p in enumerate(self.products):
             S = p.get_num_states()
@@ -232,6 +233,7 @@ class SimulationController:
             off += len(p.regression_timeline) * S * K
             self._extra_coeff_base.append(off)
             off += p._n_extra_coeffs()
+        comp.reserve_events(sum((E if want_expo else 0) + 2 * len(p.product_timeline) for p in self.products) + 16)
         expo_atom_cache: dict = {}
 
         def expo_atoms(asset):       # (numeraire, SPOT) atoms of every exposure date, once per asset
@@ -243,6 +245,7 @@ class SimulationController:
             return hit
 
         expo_arr = np.asarray(expo_times, dtype=np.float64)
+        num_atom_cache: dict = {}            # numeraire atom of a date: one lookup per distinct date instead of a request object per event
         expo_tmpl_cache: dict = {}
 
         def expo_template(asset):    # EVENT_DTYPE rows of the exposure events of one asset, product-independent fields filled
@@ -266,17 +269,25 @@ class SimulationController:
             pdates = p.product_timeline.tolist()
             assert skip or len(cash) == len(pdates)
 
+            emitted: dict = {}                 # a cash event appears twice (cashflow range + evaluation range): built once
+
             def emit_cash(ce):
-                nt = ce.time if ce.num_time is None else ce.num_time
-                num = comp.atom(AtomicRequest(AtomicRequestType.NUMERAIRE, nt), "numeraire", nt)
-                has_x = ce.kind == _abi.EV_EXERCISE or ce.x_time is not None or ce.x_asset is not None       # (an asset id may be None)
-                x = comp.atom(AtomicRequest(AtomicRequestType.SPOT), ce.x_asset, ce.time if ce.x_time is None else ce.x_time) if has_x else -1
-                co = -1 if ce.reg_idx is None else self._reg_coeff_base[p_i] + ce.reg_idx * S * K
-                if ce.coeff_params:
-                    co = self._extra_coeff_base[p_i]
-                    for k_, v_ in enumerate(ce.coeff_params):
-                        comp.coeff_init[co + k_] = float(v_)
-                return comp.add_event(ce.kind, comp.tidx(ce.time), num, x, comp.add_terms(ce.terms), co, -1, ce.strike, ce.sign, ce.aux)
+                row = emitted.get(id(ce))
+                if row is None:
+                    nt = ce.time if ce.num_time is None else ce.num_time
+                    num = num_atom_cache.get(nt)
+                    if num is None:
+                        num = num_atom_cache[nt] = comp.atom(AtomicRequest(AtomicRequestType.NUMERAIRE, nt), "numeraire", nt)
+                    has_x = ce.kind == _abi.EV_EXERCISE or ce.x_time is not None or ce.x_asset is not None       # (an asset id may be None)
+                    x = comp.atom(AtomicRequest(AtomicRequestType.SPOT), ce.x_asset, ce.time if ce.x_time is None else ce.x_time) if has_x else -1
+                    co = -1 if ce.reg_idx is None else self._reg_coeff_base[p_i] + ce.reg_idx * S * K
+                    if ce.coeff_params:
+                        co = self._extra_coeff_base[p_i]
+                        for k_, v_ in enumerate(ce.coeff_params):
+                            comp.coeff_init[co + k_] = float(v_)
+                    tr = comp.add_terms(ce.terms)
+                    row = emitted[id(ce)] = (ce.kind, comp.tidx(ce.time), num, x, tr[0], tr[1], co, -1, float(ce.strike), float(ce.sign), tuple(ce.aux))
+                return comp.add_event_row(row)
 
             cf_begin = comp.n_events
             for ce in cash:
@@ -317,6 +328,7 @@ class SimulationController:
                         emit_cash(cash[t_start])
                         t_start += 1
                 self._mc_products.append(p_i)
+                self._mc_set.add(p_i)
             ev_end = comp.n_events
             prods[p_i] = (ev_begin, ev_end, cf_begin, cf_end, self.product_to_netting_set_idx[p_i],
                           p.get_initial_state(), S, 0)
@@ -392,7 +404,7 @@ class SimulationController:
         comp = self._comp
         jobs = []
         for p_i, p in enumerate(self.products):
-            if not self._product_requires_regression(p) or p_i not in self._mc_products:
+            if p_i not in self._mc_set or not self._product_requires_regression(p):
                 continue
             sched = self._regression_schedule(p_i, p)
             jobs.append((p_i, p, sched, self._regression_atoms(sched, p.asset_ids[0])))
@@ -614,7 +626,7 @@ class SimulationController:
     def _register_regression_atoms(self):
         """atoms the LSM needs must exist before the book is uploaded"""
         for p_i, p in enumerate(self.products):
-            if self._product_requires_regression(p) and p_i in self._mc_products:
+            if p_i in self._mc_set and self._product_requires_regression(p):
                 self._regression_atoms(self._regression_schedule(p_i, p), p.asset_ids[0])
 
     def perform_prepocessing(self, request_interface: RequestInterface):   # (sic) reference spelling
