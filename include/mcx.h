@@ -382,8 +382,8 @@ int  mcx_tangent_european(mcx_handle* h, const mcx_sim* sim, const mcx_tangent_o
  *   h_dslot [n_slots][MCX_SLOT_NPARAM][NP], h_dinit [n_state][NP], h_daux [n_steps][n_slots][MCX_AUX][NP]   (simulation)
  *   d_datoms [n_atoms][5][NP] = d(a, d, b, c0, c1)                                                          (book, device)
  * Tangent tensors carry the parameter index outermost: d_dpaths [NP][T][D][ld], d_cfs [1+NP][n_ns][ld] (index 0 = value),
- * d_expo [1+NP][n_ns][n_rows][ld].  Scope: EULER; BS / Vasicek / CIR++ slots; stateless products with cashflow, plain option
- * and polynomial-exposure events; otherwise MCX_E_NOT_FUSABLE (the caller falls back to bump-and-revalue). */
+ * d_expo [1+NP][n_ns][n_rows][ld].  Scope: EULER; BS / Vasicek / CIR++ slots; cashflow, plain option, exercise and polynomial-
+ * exposure events; otherwise MCX_E_NOT_FUSABLE (the caller falls back to bump-and-revalue). */
 #define MCX_TANGENT_NP 4
 int  mcx_tangent_paths(mcx_handle* h, const mcx_sim* sim, const double* h_dslot, const double* h_dinit, const double* h_daux,
                        uint64_t seed, uint64_t path_offset, int64_t n_paths, double* d_paths, double* d_dpaths, int64_t ld,
@@ -393,6 +393,16 @@ int  mcx_tangent_paths(mcx_handle* h, const mcx_sim* sim, const double* h_dslot,
 int  mcx_tangent_lsm(mcx_handle* h, const mcx_book* book, int32_t product, int32_t first_event, int32_t num_atom, int32_t x_atom,
                      double shift, double scale, const double* d_datoms, const double* d_paths, const double* d_dpaths,
                      int64_t n_paths, int64_t ld, int32_t n_dates, double* h_moments, void* stream);
+/* the same for a product with exercise rights (Bermudan / American / FlexiCall, bermudan_option.py:93-131, flexicall.py:118-133):
+ * one step of the backward induction in dual numbers.  d_W [S][ld_w] / d_dW [NP][S][ld_w] are the cashflow cache per hypothetical
+ * state and its tangents (zero before the first step); the step rolls them over the product's cash events
+ * [roll_begin, roll_end) (relative to its first cash event) along the FROZEN exercise policy — decisions from the primal values and
+ * the book's current coefficients, tangents through the taken branch only, as on the reference's tape — and returns
+ * h_moments [1+NP][(2K-1) + S K]: sums of z^k, then of z^k numeraire W_s per state s. */
+int  mcx_tangent_lsm_step(mcx_handle* h, const mcx_book* book, int32_t product, int32_t roll_begin, int32_t roll_end, int32_t num_atom,
+                          int32_t x_atom, double shift, double scale, const double* d_datoms, const double* d_paths,
+                          const double* d_dpaths, int64_t n_paths, int64_t ld, int32_t n_dates, double* d_W, double* d_dW,
+                          int64_t ld_w, double* h_moments, void* stream);
 int  mcx_tangent_eval(mcx_handle* h, const mcx_book* book, const double* d_datoms, const double* d_coeffs, const double* d_dcoeffs,
                       const double* d_paths, const double* d_dpaths, int64_t n_paths, int64_t ld, int32_t n_dates,
                       double* d_cfs, double* d_expo,

@@ -10,9 +10,11 @@
 //   kt_cva   : sum_m relu(thr(E_m)) S(0,t_m) (1 - S(t_m,t_m+1)) (1-R) per path with tangents (cva_metric.py:62-100)
 // The derivatives of every host-computed descriptor number (model parameters per slot, psi(t) tables, initial state, the
 // closed-form coefficients of each atom) arrive as arrays next to the primal descriptors (mcx/aad.py builds them).
-// Scope: EULER scheme; Black-Scholes / Vasicek / CIR++ (stochastic and deterministic) slots; stateless products (cashflow and
-// plain option events, polynomial and analytic Black-Scholes exposures); thresholds and MPoR collateral in the metric kernels.
-// Anything else keeps the common-random-number bump path.
+//   kt_lsm_step : the same for products with exercise rights (Bermudan / American / FlexiCall): the cashflow cache rolled back
+//              along the FROZEN exercise policy in dual numbers, moments per hypothetical state
+// Scope: EULER scheme; Black-Scholes / Vasicek / CIR++ (stochastic and deterministic) slots; cashflow, plain option and exercise
+// events, polynomial (also state-indexed) and analytic Black-Scholes exposures; thresholds and MPoR collateral in the metric
+// kernels.  Anything else keeps the common-random-number bump path.
 #include "mcx_dual.h"
 
 namespace {
@@ -198,6 +200,152 @@ __device__ __forceinline__ DN kt_cash_event(const KTBook& b, const DevEvent& e, 
     return pay / num;
 }
 
+// ---- exercise events in dual numbers -------------------------------------------------------------------------------------------
+// The reference's tape puts NO gradient through the boolean `should_exercise` (bermudan_option.py:122-128; flexicall.py:118-133):
+// the decision is taken from the primal values — immediate value against the regression continuation value of the path's state —
+// and the tangent flows through the branch that was taken only (the immediate value, where the path exercises).
+// State-independent pieces of one MCX_EV_EXERCISE event for path i: the dual immediate value already divided by the numeraire and
+// the primal explanatory variable of the continuation polynomial.
+struct KTExercise { DN pay; double imm, x; };
+__device__ __forceinline__ KTExercise kt_exercise_value(const KTBook& b, const DevEvent& e, const KTEventIds& id, const int32_t* __restrict__ term_atom,
+                                                         int64_t i)
+{
+    KTExercise r;
+    const DN num = kt_atom(b, e.num, id.num, i);
+    DN val = dconst<NP>(0.0);
+    for (int j = e.term_begin; j < e.term_end; ++j) {
+        const DevTerm tm = ldk_struct(&b.terms[j]);
+        val = val + kt_atom(b, tm.atom, ldk(term_atom + j), i) * tm.w;
+    }
+    const DN xs = (val - e.strike) * e.sign;                         // torch.maximum(x, 0): gradient 1 for x > 0, 1/2 at the tie
+    const double w = xs.v > 0.0 ? 1.0 : (xs.v == 0.0 ? 0.5 : 0.0);
+    DN imm;
+    imm.v = fmax(xs.v, 0.0);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) imm.d[q] = w * xs.d[q];
+    r.pay = imm / num;
+    r.imm = imm.v;
+    r.x = e.coeff_off >= 0 ? kt_atom(b, e.x, id.x, i).v : 0.0;
+    return r;
+}
+__device__ __forceinline__ double kt_poly(const double* __restrict__ c, int K, double x)
+{
+    double v = 0.0, xp = 1.0;
+    for (int k = 0; k < K; ++k) { v = fma(c[k], xp, v); xp *= x; }
+    return v;
+}
+// decision of a path in state s (the PRIMAL coefficients of the base run: the same decisions as its primal pass); s is decremented
+__device__ __forceinline__ bool kt_exercises(const DevEvent& e, const double* __restrict__ coeffs, int K, const KTExercise& ev, int& s)
+{
+    double cont = 0.0, cont_ex = 0.0;
+    if (e.coeff_off >= 0) {
+        cont = kt_poly(coeffs + e.coeff_off + s * K, K, ev.x);
+        if (e.aux[0] == 1.0 && s > 0) cont_ex = kt_poly(coeffs + e.coeff_off + (s - 1) * K, K, ev.x);      // flexicall.py:118-133
+    }
+    const bool ex = (ev.imm + cont_ex > cont) && (s > 0);
+    if (ex) s -= 1;
+    return ex;
+}
+
+// ---- LSM step of an exercise product with tangents: the cashflow cache is rolled one window back along the frozen policy ----------
+// (controller.py:316-383; K3's k3_roll in dual numbers).  W [S][ld_w] and dW [NP][S][ld_w] hold, per hypothetical state, the
+// discounted cashflows after the previous regression date and their tangents; moments [1+NP][(2K-1) + S K].
+struct KTSArgs {
+    KTBook b;
+    const KTEventIds* __restrict__ ev_ids;
+    const int32_t* __restrict__ term_atom;
+    const double* __restrict__ coeffs;         // primal coefficients of the base run (decisions)
+    double* __restrict__ W;
+    double* __restrict__ dW;
+    DevAtom num, x;
+    double shift, scale;
+    double* __restrict__ partials;             // [gridDim.x][1+NP][NM]
+    int64_t ld_w, w_stride;                    // w_stride = S * ld_w (between tangents)
+    int32_t roll_begin, roll_end, num_id, x_id;
+};
+
+template <int K, int S>
+__global__ __launch_bounds__(MCX_BLOCK) void kt_lsm_step(const KTSArgs a)
+{
+    constexpr int NM = (2 * K - 1) + S * K;
+    double acc[1 + NP][NM];
+#pragma unroll
+    for (int q = 0; q <= NP; ++q)
+#pragma unroll
+        for (int m = 0; m < NM; ++m) acc[q][m] = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * MCX_BLOCK + threadIdx.x; i < a.b.n; i += (int64_t)gridDim.x * MCX_BLOCK) {
+        DN w[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            w[s].v = a.W[(int64_t)s * a.ld_w + i];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) w[s].d[q] = a.dW[q * a.w_stride + (int64_t)s * a.ld_w + i];
+        }
+        if (a.roll_end > a.roll_begin) {
+            int st[S];
+            DN sv[S];
+#pragma unroll
+            for (int s0 = 0; s0 < S; ++s0) { st[s0] = s0; sv[s0] = dconst<NP>(0.0); }
+            for (int q = a.roll_begin; q < a.roll_end; ++q) {                   // controller.py:333-341
+                const DevEvent e = ldk_struct(&a.b.events[q]);
+                const KTEventIds id = ldk_struct(&a.ev_ids[q]);
+                if (e.kind == MCX_EV_EXERCISE) {
+                    const KTExercise ev = kt_exercise_value(a.b, e, id, a.term_atom, i);      // once per path and date, not per state
+#pragma unroll
+                    for (int s0 = 0; s0 < S; ++s0)
+                        if (kt_exercises(e, a.coeffs, K, ev, st[s0])) sv[s0] = sv[s0] + ev.pay;
+                } else {
+                    const DN v = kt_cash_event(a.b, e, id, a.term_atom, i);
+#pragma unroll
+                    for (int s0 = 0; s0 < S; ++s0) sv[s0] = sv[s0] + v;
+                }
+            }
+            DN wn[S];
+#pragma unroll
+            for (int s0 = 0; s0 < S; ++s0) {
+                DN tail = w[0];
+#pragma unroll
+                for (int q = 1; q < S; ++q) if (st[s0] == q) tail = w[q];        // lookup_state_values (product.py:150-155)
+                wn[s0] = sv[s0] + tail;
+            }
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                w[s] = wn[s];
+                a.W[(int64_t)s * a.ld_w + i] = wn[s].v;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) a.dW[q * a.w_stride + (int64_t)s * a.ld_w + i] = wn[s].d[q];
+            }
+        }
+        const DN num = kt_atom(a.b, a.num, a.num_id, i);                                   // :368
+        const DN z = (kt_atom(a.b, a.x, a.x_id, i) - a.shift) * a.scale;
+        DN zp = dconst<NP>(1.0);
+#pragma unroll
+        for (int k = 0; k < 2 * K - 1; ++k) {
+            acc[0][k] += zp.v;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) acc[1 + q][k] += zp.d[q];
+            if (k < K) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const DN zy = zp * (num * w[s]);
+                    acc[0][(2 * K - 1) + s * K + k] += zy.v;
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) acc[1 + q][(2 * K - 1) + s * K + k] += zy.d[q];
+                }
+            }
+            zp = zp * z;
+        }
+    }
+    __shared__ double lds[4];
+#pragma unroll
+    for (int q = 0; q <= NP; ++q)
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const double r = block_sum(acc[q][m], lds);
+            if (threadIdx.x == 0) a.partials[((int64_t)blockIdx.x * (1 + NP) + q) * NM + m] = r;
+        }
+}
+
 // ---- LSM moments with tangents ------------------------------------------------------------------------------------------
 struct KTLArgs {
     KTBook b;
@@ -281,11 +429,16 @@ __global__ __launch_bounds__(MCX_BLOCK) void kt_eval(const KTEArgs a)
     for (int p = 0; p < a.n_products; ++p) {
         const DevProduct pr = ldk_struct(&a.products[p]);
         DN acc = dconst<NP>(0.0);
+        int state = pr.init_state;                                                        // rights left (exercise products)
         for (int q = pr.ev_begin; q < pr.ev_end; ++q) {
             const DevEvent e = ldk_struct(&a.b.events[q]);
             const KTEventIds id = ldk_struct(&a.ev_ids[q]);
             if (e.kind <= MCX_EV_OPTION) {
                 acc = acc + kt_cash_event(a.b, e, id, a.term_atom, i);
+            } else if (e.kind == MCX_EV_EXERCISE) {
+                // decision from the primal values, tangent through the taken branch only (bermudan_option.py:93-131)
+                const KTExercise ev = kt_exercise_value(a.b, e, id, a.term_atom, i);
+                if (kt_exercises(e, a.coeffs, K, ev, state)) acc = acc + ev.pay;
             } else {                                                                      // exposures (controller.py:430-447)
                 DN v = dconst<NP>(0.0);
                 if (e.kind == MCX_EV_EXPO_BS) {
@@ -316,8 +469,14 @@ __global__ __launch_bounds__(MCX_BLOCK) void kt_eval(const KTEArgs a)
                 } else if (e.coeff_off >= 0) {
                     const DN x = kt_atom(a.b, e.x, id.x, i);
                     DN xp = dconst<NP>(1.0);
+                    // the coefficient row of the path's exercise state (product.py:150-184); stateless products: row 0
+                    const int row0 = e.coeff_off + (pr.n_states > 1 ? state * K : 0);
                     for (int k = 0; k < K; ++k) {
-                        v = v + ld_dual(ldk(a.coeffs + e.coeff_off + k), a.dcoeffs + (int64_t)(e.coeff_off + k) * NP) * xp;
+                        DN ck;
+                        ck.v = a.coeffs[row0 + k];
+#pragma unroll
+                        for (int r = 0; r < NP; ++r) ck.d[r] = a.dcoeffs[(int64_t)(row0 + k) * NP + r];
+                        v = v + ck * xp;
                         xp = xp * x;
                     }
                     v = v / kt_atom(a.b, e.num, id.num, i);
@@ -612,6 +771,63 @@ extern "C" int mcx_tangent_lsm(mcx_handle* h, const mcx_book* b, int32_t product
     return 0;
 }
 
+extern "C" int mcx_tangent_lsm_step(mcx_handle* h, const mcx_book* b, int32_t product, int32_t roll_begin, int32_t roll_end, int32_t num_atom,
+                                    int32_t x_atom, double shift, double scale, const double* d_datoms, const double* d_paths,
+                                    const double* d_dpaths, int64_t n_paths, int64_t ld, int32_t n_dates, double* d_W, double* d_dW,
+                                    int64_t ld_w, double* h_moments, void* stream)
+{
+    if (!h || !b || !d_datoms || !d_paths || !d_dpaths || !d_W || !d_dW || !h_moments) return -1;
+    if (product < 0 || product >= b->n_products) MCX_FAIL(h, -2, "mcx_tangent_lsm_step: product out of range");
+    const DevProduct& pr = b->h_products[product];
+    const int n_cf = pr.cf_end - pr.cf_begin;
+    if (roll_begin < 0 || roll_end < roll_begin || roll_end > n_cf) MCX_FAIL(h, -2, "mcx_tangent_lsm_step: roll window out of range");
+    if (ld < n_paths || ld_w < n_paths) MCX_FAIL(h, -2, "mcx_tangent_lsm_step: leading dimension < n_paths");
+    for (int q = pr.cf_begin + roll_begin; q < pr.cf_begin + roll_end; ++q) {
+        const DevEvent& e = b->h_events[q];
+        const bool ok = e.kind == MCX_EV_CASHFLOW || (e.kind == MCX_EV_OPTION && e.aux[0] == 0.0) ||
+                        (e.kind == MCX_EV_EXERCISE && (e.aux[0] == 0.0 || e.aux[0] == 1.0));
+        if (!ok) MCX_FAIL(h, MCX_E_NOT_FUSABLE, "mcx_tangent_lsm_step: event %d (kind %d, mode %g) has no tangent form", q, e.kind, e.aux[0]);
+        if (e.kind != MCX_EV_CASHFLOW)
+            for (int j = e.term_begin; j < e.term_end; ++j)
+                if (b->h_terms[j].den >= 0) MCX_FAIL(h, MCX_E_NOT_FUSABLE, "mcx_tangent_lsm_step: option over per-term denominators");
+    }
+    if (num_atom < 0 || num_atom >= b->n_atoms || x_atom < 0 || x_atom >= b->n_atoms) MCX_FAIL(h, -2, "mcx_tangent_lsm_step: atom out of range");
+    const int K = b->n_basis, S = pr.n_states, NM = (2 * K - 1) + S * K;
+    if (n_paths <= 0) { memset(h_moments, 0, sizeof(double) * (size_t)(1 + NP) * NM); return 0; }
+    hipStream_t s = (hipStream_t)stream;
+    DevBuf ev_ids, term_atom;
+    if (int rc = upload_ids(h, b, ev_ids, term_atom, s)) return rc;
+    const int grid = mcx_grid_for(n_paths, MCX_BLOCK, 2 * h->n_cu);
+    const int count = (1 + NP) * NM;
+    if ((size_t)(grid + 1) * count * sizeof(double) > h->ws_bytes || (size_t)count * sizeof(double) > h->pinned_bytes)
+        MCX_FAIL(h, -2, "mcx_tangent_lsm_step: workspace too small");
+    KTSArgs a;
+    memset(&a, 0, sizeof(a));
+    fill_book(h, b, d_datoms, d_paths, d_dpaths, n_paths, ld, n_dates, &a.b);
+    a.ev_ids = (const KTEventIds*)ev_ids.p; a.term_atom = (const int32_t*)term_atom.p; a.coeffs = b->d_coeffs;
+    a.W = d_W; a.dW = d_dW; a.ld_w = ld_w; a.w_stride = (int64_t)S * ld_w;
+    a.num = flat_atom(b, num_atom); a.x = flat_atom(b, x_atom); a.num_id = num_atom; a.x_id = x_atom; a.shift = shift; a.scale = scale;
+    a.partials = h->d_ws; a.roll_begin = pr.cf_begin + roll_begin; a.roll_end = pr.cf_begin + roll_end;
+    bool launched = true;
+#define MCX_KTS(KK, SS) hipLaunchKernelGGL((kt_lsm_step<KK, SS>), dim3(grid), dim3(MCX_BLOCK), 0, s, a)
+    switch (K * 16 + S) {
+    case 2 * 16 + 1: MCX_KTS(2, 1); break;  case 2 * 16 + 2: MCX_KTS(2, 2); break;  case 2 * 16 + 3: MCX_KTS(2, 3); break;
+    case 3 * 16 + 1: MCX_KTS(3, 1); break;  case 3 * 16 + 2: MCX_KTS(3, 2); break;  case 3 * 16 + 3: MCX_KTS(3, 3); break;
+    case 3 * 16 + 4: MCX_KTS(3, 4); break;  case 4 * 16 + 1: MCX_KTS(4, 1); break;  case 4 * 16 + 2: MCX_KTS(4, 2); break;
+    default: launched = false; break;
+    }
+#undef MCX_KTS
+    if (!launched) MCX_FAIL(h, MCX_E_NOT_FUSABLE, "mcx_tangent_lsm_step: (basis=%d, states=%d) has no instantiation", K, S);
+    MCX_HIP(h, hipGetLastError());
+    double* d_out = h->d_ws + (size_t)grid * count;
+    hipLaunchKernelGGL(kt_sum_partials, dim3((count + 63) / 64), dim3(64), 0, s, h->d_ws, count, grid, d_out);
+    MCX_HIP(h, hipGetLastError());
+    MCX_HIP(h, hipMemcpyAsync(h->h_pinned, d_out, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, s));
+    MCX_HIP(h, hipStreamSynchronize(s));
+    memcpy(h_moments, h->h_pinned, sizeof(double) * (size_t)count);
+    return 0;
+}
+
 extern "C" int mcx_tangent_eval(mcx_handle* h, const mcx_book* b, const double* d_datoms, const double* d_coeffs, const double* d_dcoeffs,
                                 const double* d_paths, const double* d_dpaths, int64_t n_paths, int64_t ld, int32_t n_dates,
                                 double* d_cfs, double* d_expo, const int32_t* h_ev_param, void* stream)
@@ -620,13 +836,13 @@ extern "C" int mcx_tangent_eval(mcx_handle* h, const mcx_book* b, const double* 
     if (n_paths <= 0) return 0;
     for (int p = 0; p < b->n_products; ++p) {
         const DevProduct& pr = b->h_products[p];
-        if (pr.n_states != 1) MCX_FAIL(h, MCX_E_NOT_FUSABLE, "mcx_tangent_eval: product %d has exercise states", p);
         for (int q = pr.ev_begin; q < pr.ev_end; ++q) {
             const DevEvent& e = b->h_events[q];
             const bool ok = e.kind == MCX_EV_CASHFLOW || (e.kind == MCX_EV_OPTION && e.aux[0] == 0.0) || e.kind == MCX_EV_EXPO_POLY ||
-                            (e.kind == MCX_EV_EXPO_BS && h_ev_param != nullptr);
+                            (e.kind == MCX_EV_EXPO_BS && h_ev_param != nullptr) ||
+                            (e.kind == MCX_EV_EXERCISE && pr.n_states > 1 && (e.aux[0] == 0.0 || e.aux[0] == 1.0));
             if (!ok) MCX_FAIL(h, MCX_E_NOT_FUSABLE, "mcx_tangent_eval: event %d (kind %d) has no tangent form", q, e.kind);
-            if (e.kind == MCX_EV_OPTION)
+            if (e.kind == MCX_EV_OPTION || e.kind == MCX_EV_EXERCISE)
                 for (int j = e.term_begin; j < e.term_end; ++j)
                     if (b->h_terms[j].den >= 0) MCX_FAIL(h, MCX_E_NOT_FUSABLE, "mcx_tangent_eval: option over per-term denominators");
         }

@@ -23,7 +23,7 @@ _EXPORTS = [
     "mcx_comm_unique_id", "mcx_comm_init", "mcx_comm_destroy", "mcx_allreduce_f64", "mcx_allgather_f64",
     "mcx_book_create", "mcx_book_destroy", "mcx_book_set_coeffs", "mcx_eval_book", "mcx_resolve_atoms",
     "mcx_lsm_stats", "mcx_lsm_step", "mcx_lsm_run", "mcx_lsm_solve", "mcx_lsm_step_batch", "mcx_lsm_step_batch_dev", "mcx_lsm_solve_batch", "mcx_book_get_coeffs", "mcx_book_set_coeffs_batch", "mcx_book_set_bridge_rng", "mcx_book_set_exercise_replay",
-    "mcx_fused_is_straight_line", "mcx_tangent_paths", "mcx_tangent_lsm", "mcx_tangent_eval", "mcx_tangent_cva", "mcx_tangent_profiles", "mcx_tangent_pick",
+    "mcx_fused_is_straight_line", "mcx_tangent_paths", "mcx_tangent_lsm", "mcx_tangent_lsm_step", "mcx_tangent_eval", "mcx_tangent_cva", "mcx_tangent_profiles", "mcx_tangent_pick",
     "mcx_box_muller", "mcx_tangent_european", "mcx_fused_create", "mcx_fused_destroy", "mcx_fused_num_records", "mcx_fused_run", "mcx_fused_eval_paths", "mcx_fused_run_device", "mcx_fused_eval_paths_device", "mcx_fused_set_timing", "mcx_fused_kernel_times",
     "mcx_value_poly_fit", "mcx_book_collapse_values", "mcx_book_value_poly_info", "mcx_rows_minmax",
     "mcx_reduce_vector", "mcx_reduce_profiles", "mcx_reduce_cva", "mcx_unsecured", "mcx_select_hist", "mcx_select_hist_dev", "mcx_select_narrow", "mcx_select_bracket", "mcx_select_hist_rows",
@@ -339,6 +339,23 @@ class HipBackend:
             self.h, book.ptr, C.c_int32(product), C.c_int32(first_event), C.c_int32(num_atom), C.c_int32(x_atom),
             C.c_double(shift), C.c_double(scale), _vp(datoms.data_ptr()), _vp(paths.data_ptr()), _vp(dpaths.data_ptr()),
             C.c_int64(n), C.c_int64(n), C.c_int32(paths.shape[0]), _abi.ptr(out), self._stream()), "mcx_tangent_lsm")
+        return out
+
+    def tangent_lsm_step(self, book, product: int, roll_begin: int, roll_end: int, num_atom: int, x_atom: int, shift: float,
+                         scale: float, datoms: torch.Tensor, paths: torch.Tensor, dpaths: torch.Tensor, W: torch.Tensor,
+                         dW: torch.Tensor) -> np.ndarray:
+        """one backward step of an exercise product's regression in dual numbers (mcx_tangent_lsm_step): W [S][n], dW [NP][S][n]
+        are rolled in place; returns the moments [1+NP][(2K-1) + S K]"""
+        K, S = book.plan.n_basis, W.shape[0]
+        NP = _abi.TANGENT_NP
+        n = paths.shape[2]
+        assert W.is_contiguous() and dW.is_contiguous() and dW.shape == (NP, S, W.shape[1]) and W.shape[1] >= n
+        out = np.zeros((1 + NP, (2 * K - 1) + S * K))
+        self._check(self.lib.mcx_tangent_lsm_step(
+            self.h, book.ptr, C.c_int32(product), C.c_int32(roll_begin), C.c_int32(roll_end), C.c_int32(num_atom), C.c_int32(x_atom),
+            C.c_double(shift), C.c_double(scale), _vp(datoms.data_ptr()), _vp(paths.data_ptr()), _vp(dpaths.data_ptr()),
+            C.c_int64(n), C.c_int64(n), C.c_int32(paths.shape[0]), _vp(W.data_ptr()), _vp(dW.data_ptr()), C.c_int64(W.shape[1]),
+            _abi.ptr(out), self._stream()), "mcx_tangent_lsm_step")
         return out
 
     def tangent_eval(self, book, datoms: torch.Tensor, coeffs: torch.Tensor, dcoeffs: torch.Tensor, paths: torch.Tensor,

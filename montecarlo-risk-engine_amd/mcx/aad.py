@@ -280,6 +280,17 @@ def _solve_dual(mom: np.ndarray, K: int, shift: float, scale: float, degenerate:
     return c, dc
 
 
+def _solve_dual_states(mom: np.ndarray, K: int, S: int, shift: float, scale: float, degenerate: bool, n_par: int):
+    """_solve_dual for the S right-hand sides of an exercise product (moments of mcx_tangent_lsm_step: sums of z^k, then of
+    z^k Y_s per state s): c [S][K], dc [n_par][S][K]"""
+    c, dc = np.zeros((S, K)), np.zeros((n_par, S, K))
+    for s_ in range(S):
+        sel = list(range(2 * K - 1)) + list(range(2 * K - 1 + s_ * K, 2 * K - 1 + (s_ + 1) * K))
+        cs, dcs = _solve_dual(mom[:, sel], K, shift, scale, degenerate, n_par)
+        c[s_], dc[:, s_, :] = cs, dcs
+    return c, dc
+
+
 def run_with_tangent_book(sc):
     """d PV / d theta and d CVA / d theta in forward mode through pre-simulation, regression and main simulation."""
     import copy
@@ -293,8 +304,10 @@ def run_with_tangent_book(sc):
     if any(m.metric_type not in (MetricType.PV, MetricType.CVA, MetricType.EPE, MetricType.ENE, MetricType.CE, MetricType.EEPE,
                                  MetricType.PFE) or not m._native for m in rm.metrics):
         raise _NoTangentForm("metric")
-    if any(p.get_num_states() != 1 for p in sc.products) or len(sc.products) > 64:
+    if len(sc.products) > 64:
         raise _NoTangentForm("products")
+    if any(p.get_num_states() > 1 for p in sc.products) and not hasattr(sc.backend, "tangent_lsm_step"):
+        raise _NoTangentForm("exercise products")
     if any(sc._can_skip_monte_carlo_for_product(p) for p in sc.products):
         raise _NoTangentForm("analytic shortcuts")
     t0 = time.perf_counter()
@@ -361,6 +374,8 @@ def run_with_tangent_book(sc):
     n_eval = [len(res0.results[0][m_i]) for m_i in range(n_metrics)]
     grads = [[[[0.0] * P for _ in range(n_eval[m_i])] for m_i in range(n_metrics)] for _ in range(n_ns)]     # [ns][metric][eval][param]
     jobs = [(p_i, p) for p_i, p in enumerate(sc.products) if p_i in base._mc_set and base._product_requires_regression(p)]
+    has_exercise = any(p.get_num_states() > 1 for p in sc.products)
+    base_coeffs = np.asarray(be.book_get_coeffs(base.book), dtype=np.float64)[:n_coeffs] if (has_exercise and n_coeffs) else None
     rows = base.metric_exposure_indices.numpy().astype(np.int32) if rm.requires_exposure_profiles() else np.zeros(0, dtype=np.int32)
 
     def mean_of(vec):
@@ -372,6 +387,10 @@ def run_with_tangent_book(sc):
         dslot, dinit, daux = pad(dd["slots"]), pad(dd["init"]), pad(dd["aux"])
         datoms = be.from_numpy(pad(dd["atoms"]))
         coeffs, dcoeffs = np.zeros(max(n_coeffs, 1)), np.zeros((max(n_coeffs, 1), NP))
+        if has_exercise and n_coeffs:
+            # exercise decisions are taken from the PRIMAL coefficients of the base run (the reference's tape has no gradient through
+            # `should_exercise`, bermudan_option.py:122-128): every row starts from them, the exposure rows get their tangents below
+            coeffs[:n_coeffs] = base_coeffs
         t1 = time.perf_counter()
         if jobs:
             off, n_pre = shard.split(sc.num_paths_presim)
@@ -384,6 +403,25 @@ def run_with_tangent_book(sc):
             lo, hi = g[:, :, 0].min(axis=0), g[:, :, 1].max(axis=0)
             x_range = {x: (lo[i], hi[i]) for i, x in enumerate(x_ids)}
             for p_i, p, sched, atoms in plan:
+                S = p.get_num_states()
+                if S > 1:
+                    # backward induction with the cashflow cache of every hypothetical state rolled in dual numbers along the
+                    # frozen policy (mcx_tangent_lsm_step); the coefficient tangents of the exposure rows feed the main pass
+                    W, dW = be.zeros(S, n_pre), be.zeros(NP, S, n_pre)
+                    for (t_reg, r0, r1, _prod_idx, expo_idx), (num, x) in zip(sched, atoms):
+                        xmin, xmax = x_range[x]
+                        degenerate = not (xmax > xmin)
+                        shift = 0.5 * (xmin + xmax) if not degenerate else xmin
+                        scale = 2.0 / (xmax - xmin) if not degenerate else 1.0
+                        mom = shard.all_reduce_np(be.tangent_lsm_step(book, p_i, r0, r1, num, x, shift, scale, datoms, paths_pre,
+                                                                      dpaths_pre, W, dW))
+                        if expo_idx is None:
+                            continue
+                        c, dc = _solve_dual_states(mom, K, S, shift, scale, degenerate, NP)
+                        o = base._expo_coeff_base[p_i] + expo_idx * S * K
+                        dcoeffs[o:o + S * K] = dc.reshape(NP, S * K).T
+                    del W, dW
+                    continue
                 pdates = np.asarray([float(t) for t in p.product_timeline])
                 for (t_reg, _r0, _r1, _prod_idx, expo_idx), (num, x) in zip(sched, atoms):
                     if expo_idx is None:

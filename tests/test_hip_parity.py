@@ -345,6 +345,27 @@ def test_lsm_sensitivities_against_reference_autograd(name, hip):
     check_lsm_sensitivities(sc, g, res)
 
 
+def test_exercise_products_take_the_forward_mode_path(hip):
+    """Bermudan swaption sensitivities in ONE forward-mode pass (kt_lsm_step / kt_eval: exercise decisions from the primal values,
+    tangents through the taken branch only — the reference's tape has no gradient through `should_exercise`,
+    bermudan_option.py:122-128) against the reference's autograd, and against the 2P replayed bump runs they replace"""
+    from test_oracle_golden import check_lsm_sensitivities
+    sc, g = cases.make_controller("bermudan_swaption_aad", hip)
+    res = sc.run_simulation()
+    assert sc.timings.get("tangent") and sc.timings["forward_mode_passes"] == 1, sc.timings
+    check_lsm_sensitivities(sc, g, res)
+    sb, _ = cases.make_controller("bermudan_swaption_aad", hip)
+    sb.forward_mode = False
+    rb = sb.run_simulation()
+    assert not sb.timings.get("tangent")
+    for ns_i in range(len(res.derivatives)):
+        for m_i in range(len(res.derivatives[ns_i])):
+            a = np.array(res.derivatives[ns_i][m_i], dtype=np.float64)
+            b = np.array(rb.derivatives[ns_i][m_i], dtype=np.float64)
+            scale = np.abs(b).max(axis=1, keepdims=True) + 1e-12
+            assert np.all(np.abs(a - b) <= 2e-6 * scale + 1e-9), (ns_i, m_i, a, b)
+
+
 def test_basket_anchors_of_the_reference_tests(hip):
     """tests/pytests/test_model_config.py:18-71 and test_pv_basket_option.py:16-69 at their own sizes: arithmetic basket 12.60,
     geometric basket = its closed form 10.9551100513373 (ModelConfig of 4 BS models, 1 M paths; BlackScholesMulti with the

@@ -108,6 +108,25 @@ def config5(be):
                 fused=sc._fused is not None, reason=getattr(be, "not_fusable_reason", None))
 
 
+def config5_aad(be):
+    """config 5 with differentiate=True: d EPE(t) / d PFE(t) / d(4 Vasicek parameters) — ONE forward-mode pass through the exercise
+    policy (csrc/kt_book.hip kt_lsm_step / kt_eval) against the 2 x 4 replayed bump runs it replaces"""
+    out = dict(config="5 + sensitivities")
+    for fwd in (True, False):
+        model = VasicekModel(0.0, 0.03, 0.05, 0.1, 0.01)
+        und = InterestRateSwap(0.0, 16.0, 1.0, 0.03, 0.25, 0.25, IRSType.PAYER)
+        prod = BermudanOption(und, [0.125 * k for k in range(1, 121)], 0.0, OptionType.CALL)
+        tl = np.array([0.125 * k for k in range(0, 121)])
+        rm = RiskMetrics([EPEMetric(), PFEMetric(0.95)], exposure_timeline=tl)
+        sc = SimulationController([NettingSet(name="berm", products=[prod])], model, rm, 1 << 21, 1 << 18, 1, SS.EULER, differentiate=True, backend=be)
+        sc.forward_mode = fwd
+        res, dt = timed(sc)
+        res, dt = timed(sc)
+        d = res.get_derivatives(0, 0, evaluation_idx=8)
+        out["forward_mode" if fwd else "bumps"] = dict(seconds=dt, timings=sc.timings, epe_1y=res.results[0][0][8], depe_1y=d)
+    return out
+
+
 if __name__ == "__main__":
     be = _native.HipBackend(0)
     # an idle GPU (fresh box, minutes of imports) sits in a low power state and takes ~a second of load to reach its clocks: a
@@ -121,5 +140,5 @@ if __name__ == "__main__":
     which = [int(a) for a in sys.argv[1:]] or [2, 3, 4, 5, 6]
     for c in which:
         torch.cuda.empty_cache()        # each configuration starts from an empty caching allocator (no blocks split by the previous one)
-        r = {2: config2, 3: config3, 4: config4, 5: config5, 6: config3_aad}[c](be)
+        r = {2: config2, 3: config3, 4: config4, 5: config5, 6: config3_aad, 7: config5_aad}[c](be)
         print(json.dumps(r, default=float), flush=True)
