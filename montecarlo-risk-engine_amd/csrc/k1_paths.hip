@@ -49,10 +49,32 @@ __global__ __launch_bounds__(MCX_BLOCK) void k1_paths(const K1Args a)
     const mcx_bm_coef bc = mcx_bm_coef_load();
     const mcx_bm_vconst vc = mcx_bm_vconst_make(bc);          // Box-Muller constants kept in registers across the step loop
     for (int k = 0; k < a.n_steps; ++k) {
+        int st;
+        if constexpr (INJECT || SIG == SIG_GENERIC) {      // (run-time model dispatch: every aux entry of every slot would be live)
 #pragma unroll
-        for (int q = 0; q < PPL; ++q)
-            sim_substep<NSLOT, NZ, INJECT, SIG>(a, k, a.path_offset + (uint64_t)idx[q], idx[q], reg[q], tab, a.seed, bc, &vc);
-        const int st = ldk(&a.steps[k].store_idx);
+            for (int q = 0; q < PPL; ++q)
+                sim_substep<NSLOT, NZ, INJECT, SIG>(a, k, a.path_offset + (uint64_t)idx[q], idx[q], reg[q], tab, a.seed, bc, &vc);
+            st = ldk(&a.steps[k].store_idx);
+        } else {
+            // as in the one-launch kernel (kf_lean.hip): the scalar loads of the sub-step go out ahead of its draws, the draws of the
+            // lane's paths are staged (table reads first, the arithmetic that needs no table value covers their latency) with the
+            // unguarded root, one rare branch repeats the 2^-32 draws that may round to u = 1
+            const StepData<NSLOT, NZ> sdat = sim_step_load<NSLOT, NZ, SIG>(a, k);
+            __builtin_amdgcn_sched_barrier(0);
+            uint64_t path[PPL];
+            uint32_t st_q[PPL];
+            double zz[PPL][NZ], uu[PPL];
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) { path[q] = a.path_offset + (uint64_t)idx[q]; st_q[q] = (uint32_t)k; }
+            const bool rare = sim_draw_n<PPL, NZ, SIG, 7>(a, st_q, path, zz, uu, tab, a.seed, bc, vc);
+            if (__builtin_expect(__any(rare), 0)) {
+#pragma unroll
+                for (int q = 0; q < PPL; ++q) sim_draw<NZ, false, SIG, 7, true>(a, k, path[q], idx[q], zz[q], uu[q], tab, a.seed, bc, &vc);
+            }
+            st = -1;
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) st = sim_apply_loaded<NSLOT, NZ, SIG>(a, sdat, reg[q], zz[q], uu[q]);
+        }
         if (st >= 0)
 #pragma unroll
             for (int q = 0; q < PPL; ++q) if (live[q]) sim_store_state<NSLOT, SIG>(a, st, idx[q], reg[q], a.aux + (int64_t)k * NSLOT * MCX_AUX);

@@ -105,7 +105,10 @@ __device__ __forceinline__ void lean_date(int t, const int64_t (&i)[PPL], const 
     // program below: (1) the head of the record + the arguments, (2) the coefficient rows; and one round of LDS reads for its
     // two exponentials.  The waits of ~12 dependent scalar loads per date were a third of a wave's cycles at one or two waves
     // per SIMD.  Same arithmetic as the general path.
-    if (PPL == 1 && !(STORE && k.paths)) {          // (two paths per lane at four waves per SIMD: measured slower — 52 SGPR spills around the date — than the general program below)
+    // (the simulating kernel with two paths per lane at four waves per SIMD: measured slower — 52 SGPR spills around the date — than
+    //  the general program below; the streaming kernel has no generator state to keep and is bound by the scalar unit, which the
+    //  four SIMDs of a CU share: ~500 scalar instructions per date and wave of the general program cap it at ~4.3 TB/s)
+    if ((PPL == 1 || !STORE) && !(STORE && k.paths)) {
         const FastDateHot hot = ldk_struct((const FastDateHot*)fp);
         const bool pure_cva = (hot.flags & (64 | 128 | 256 | 2)) == (64 | 2) && !((hot.flags & 1) && (a.cfs != nullptr || a.rec_pv[0] >= 0)) &&
                               a.expo == nullptr && a.n_basis == 3 && hot.c_b != 0.0;
@@ -404,7 +407,12 @@ __global__ __launch_bounds__(MCX_BLOCK, MCX_LEAN_WAVES) void kf_lean(const Fused
                 const mcx_bm_vconst vc = mcx_bm_vconst_make<BMB>(bc);  // constants kept in registers across the run of sub-steps
 #pragma unroll 1
                 while (st < 0 && step < n_steps) {
-                    {
+                    if constexpr (SIG == SIG_GENERIC) {
+                        // run-time model dispatch (every aux entry of every slot would have to be loaded ahead): path after path
+#pragma unroll
+                        for (int q = 0; q < PPL; ++q) sim_substep<NSLOT, NZ, INJECT, SIG, BMB, true>(k, step, path[q], i[q], reg[q], tab, seed, bc, &vc);   // POS: mcx_fused_create
+                        st = ldk(&k.steps[step].store_idx);
+                    } else {
                         // draws of all the lane's paths in ONE basic block (unguarded root, pair_from_words), one rare branch for the
                         // 2^-32 draws that may round to u = 1, then the state updates
                         double zz[PPL][NZ], uu[PPL];
