@@ -329,10 +329,11 @@ def main():
                     model_ms = sum(cls[k] * ns[k] for k in cls) * (n_local / 64.0) * S / 1024.0 * 1e-6
                     alu = {"bound": "f64 VALU issue", "valu_insts_per_path_step": per_ps, "mix_per_path_step": cls,
                            "issue_ns_per_wave_instruction_per_simd": ns, "modelled_ms": model_ms, "frac": model_ms / k1_ms,
-                           "note": "issue costs are the SUSTAINED rates tools/ubench_valu measures with every CU busy (wall time per wave64 "
-                                   "instruction per SIMD): v_fma_f64 2.36 ns = 55 of the 78.6 TFLOP/s f64 vector spec (GRBM_GUI_ACTIVE puts the "
-                                   "clock near 2.27 GHz in these runs, i.e. ~5.3 clk per instruction, not the nominal 4); frac ~ 1 = the kernel "
-                                   "runs at the rate the VALU pipe sustains for its instruction mix",
+                           "note": "issue costs are the SUSTAINED rates tools/ubench_valu measures with every CU busy: HIP events around ONE "
+                                   ">= 10 ms launch per instruction class, 8 waves per SIMD (profiles/r03_ubench_valu.txt; the shader clock "
+                                   "during those launches, 2.15-2.39 GHz by class, is in profiles/r03_ubench_valu_clock_mhz.txt: v_fma_f64 "
+                                   "1.94 ns = 4.2 clk at the 2.18 GHz it holds); frac = modelled VALU issue time / kernel time — what is left "
+                                   "is scalar work and waits the four waves of a SIMD do not fully overlap",
                            "source": "profiles/counters.json (tools/measure_counters.sh)"}
             else:
                 counters_note = "profiles/counters.json was measured on other kernel sources: traffic / alu omitted"

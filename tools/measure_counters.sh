@@ -24,12 +24,12 @@ res = {"kernel_source_sha": bench.kernel_source_sha(),
 # measured by tools/ubench_valu in this very call: under f64 VALU load the chip does NOT hold 2.4 GHz
 ub = {}
 for line in open(f"{out}/ubench_valu.txt"):
-    name = line[:28].strip()
-    if "ns wall" in line:
-        ub[name] = float(line.split("s_memtime-ticks,")[1].split("ns wall")[0])
+    name = line[:36].strip()
+    if "ns per wave-instr" in line:
+        ub[name] = float(line.split(")")[-2].split("ns per wave-instr")[0].strip().split()[-1])
 res["issue_ns"] = {"f64": ub["v_fma_f64"], "mad_u64_u32": ub["v_mad_u64_u32 (+shift)"], "int32": ub["xor/shift int (3 ops)"],
                    "rsq_f64": ub["v_rsq_f64"], "minmax_f64": ub["v_max_f64"]}
-res["issue_ns_source"] = "tools/ubench_valu: wall time of 20 launches / wave-instructions per SIMD (8 independent chains per lane)"
+res["issue_ns_source"] = "tools/ubench_valu: HIP events around ONE >= 10 ms launch / wave-instructions per SIMD (8 independent chains per lane, 8 waves per SIMD)"
 res["substep_mix_per_path"] = json.load(open(f"{out}/asm_mix.json"))["per_path_substep"]
 for k, v in sq.items():
     e = dict(v)

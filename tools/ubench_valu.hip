@@ -1,18 +1,20 @@
-// Micro-benchmark: issue throughput (cycles per wave-instruction per SIMD) of the VALU ops the path kernel is made of.
-// Many independent chains per lane, 8 waves/SIMD resident, s_memtime around an unrolled loop.
+// Micro-benchmark: sustained issue cost (ns per wave64 instruction per SIMD, every CU busy, 8 waves per SIMD) of the VALU ops the
+// path kernels are made of.  NCH independent chains per lane; ONE launch per figure, >= 10 ms long (ITER is sized for it), timed
+// by HIP events around that launch alone.  The shader clock the chip holds during these launches comes from the same binary run
+// under `rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace` (tools/measure_clock.sh: busy cycles / kernel duration / 8 XCDs).
+// (Round 2 also printed s_memtime deltas: s_memtime runs off a constant reference clock, not the shader clock, and a delta taken
+//  inside a 38 us launch includes the wave's ramp-in — the column disagreed with the wall clock by 2.5x and is gone.)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>
-#define ITER 256
 #define NCH 8
 template <int OP>
-__global__ __launch_bounds__(256) void bench(double* out, uint64_t* cyc, double seed)
+__global__ __launch_bounds__(256) void bench(double* out, double seed, int iters)
 {
     double a[NCH]; uint32_t u[NCH]; uint64_t w[NCH];
     for (int c = 0; c < NCH; ++c) { a[c] = seed + c + threadIdx.x * 1e-3; u[c] = (uint32_t)(threadIdx.x * 2654435761u + c); w[c] = u[c]; }
-    uint64_t t0 = __builtin_amdgcn_s_memtime();
 #pragma unroll 1
-    for (int it = 0; it < ITER; ++it) {
+    for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             if (OP == 0) a[c] = __builtin_fma(a[c], 1.0000001, 0.5);
@@ -32,31 +34,34 @@ __global__ __launch_bounds__(256) void bench(double* out, uint64_t* cyc, double 
             if (OP == 14) a[c] = __builtin_amdgcn_fract(a[c]) + 1.0;
         }
     }
-    uint64_t t1 = __builtin_amdgcn_s_memtime();
     double s = 0; for (int c = 0; c < NCH; ++c) s += a[c] + u[c] + (double)w[c];
     out[blockIdx.x * 256 + threadIdx.x] = s;
-    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 template <int OP> void run(const char* name, int ninstr_per_chain)
 {
-    double* out; uint64_t* cyc; const int blocks = 256 * 8;   // 8 blocks of 4 waves per CU = 8 waves per SIMD
-    hipMalloc(&out, blocks * 256 * 8); hipMalloc(&cyc, blocks * 8);
+    double* out; const int blocks = 256 * 8;   // 8 blocks of 4 waves per CU = 8 waves per SIMD
+    hipMalloc(&out, blocks * 256 * 8);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(bench<OP>, dim3(blocks), dim3(256), 0, 0, out, cyc, 1.5);
+    // size the launch: a short probe, then ITER for ~20 ms
+    int iters = 4096;
+    hipLaunchKernelGGL(bench<OP>, dim3(blocks), dim3(256), 0, 0, out, 1.5, iters);
     hipEventRecord(e0, 0);
-    for (int r = 0; r < 20; ++r) hipLaunchKernelGGL(bench<OP>, dim3(blocks), dim3(256), 0, 0, out, cyc, 1.5);
+    hipLaunchKernelGGL(bench<OP>, dim3(blocks), dim3(256), 0, 0, out, 1.5, iters);
     hipEventRecord(e1, 0);
     hipDeviceSynchronize();
     float ms = 0; hipEventElapsedTime(&ms, e0, e1);
-    uint64_t* h = new uint64_t[blocks]; hipMemcpy(h, cyc, blocks * 8, hipMemcpyDeviceToHost);
-    double avg = 0; for (int b = 0; b < blocks; ++b) avg += h[b]; avg /= blocks;
-    // each wave issues ITER*NCH*ninstr instr; 8 waves share a SIMD -> cycles per wave-instruction at full occupancy:
-    double per = avg / (ITER * NCH * ninstr_per_chain) / 8.0;
-    // wall clock: 20 launches, each SIMD issues 8 waves x ITER*NCH*ninstr wave-instructions (+ ~5 % prologue/epilogue)
-    double ns_per = ms * 1e6 / 20.0 / (8.0 * ITER * NCH * ninstr_per_chain);
-    printf("%-28s %8.0f ticks/wave-loop  => %.2f s_memtime-ticks, %.3f ns wall per wave-instr per SIMD (8 waves resident) = %.2f clk at 2.4 GHz\n",
-           name, avg, per, ns_per, ns_per * 2.4);
-    hipFree(out); hipFree(cyc); delete[] h;
+    iters = (int)(iters * (20.0 / (ms > 1e-3 ? ms : 1e-3)));
+    if (iters < 100000) iters = 100000;
+    hipLaunchKernelGGL(bench<OP>, dim3(blocks), dim3(256), 0, 0, out, 1.5, iters);      // clocks up
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(bench<OP>, dim3(blocks), dim3(256), 0, 0, out, 1.5, iters);      // the ONE timed launch
+    hipEventRecord(e1, 0);
+    hipDeviceSynchronize();
+    hipEventElapsedTime(&ms, e0, e1);
+    // each SIMD issues 8 waves x iters*NCH*ninstr wave-instructions
+    const double ns_per = ms * 1e6 / (8.0 * (double)iters * NCH * ninstr_per_chain);
+    printf("%-36s launch %7.2f ms (ITER %8d)  %.3f ns per wave-instr per SIMD (8 waves resident)\n", name, ms, iters, ns_per);
+    hipFree(out);
 }
 int main()
 {
