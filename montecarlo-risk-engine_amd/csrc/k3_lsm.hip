@@ -529,6 +529,25 @@ __global__ void k3_solve(const double* __restrict__ m, const K3Solve q, double* 
     k3_solve_body(m, q, coeffs, table, status);
 }
 
+// finish + solve in ONE launch (mcx_lsm_run on one GPU: the moments need no all-reduce between the two): wave q of a 1024-thread
+// block sums moment q over the step kernel's per-block partials (fixed order: deterministic), thread 0 solves.  Two launches per
+// regression date instead of three — 121 dates of a Bermudan are latency: ~5 us + a kernel boundary each.
+__global__ __launch_bounds__(1024) void k3_finish_solve(const double* __restrict__ partials, int nm, int n_blocks, double* __restrict__ mom_out,
+                                                        const K3Solve q, double* __restrict__ coeffs, double* __restrict__ table,
+                                                        int32_t* __restrict__ status)
+{
+    __shared__ double m[(2 * MCX_MAX_BASIS - 1) + MCX_MAX_STATES * MCX_MAX_BASIS];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int j = wv; j < nm; j += 16) {
+        double s = 0.0;
+        for (int b = lane; b < n_blocks; b += MCX_WAVE) s += partials[(int64_t)b * nm + j];
+        s = wave_sum(s);
+        if (lane == 0) { m[j] = s; mom_out[j] = s; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) k3_solve_body(m, q, coeffs, table, status);
+}
+
 template <int K, int S>
 void launch_k3(const K3Args& a, int grid, bool mfma, hipStream_t s)
 {
@@ -617,7 +636,8 @@ extern "C" int mcx_rows_minmax(mcx_handle* h, const double* d_x, int32_t n_rows,
 // roll + moments of one (product, date) on the stream: d_moments[NM] (device)
 static int lsm_step_launch(mcx_handle* h, const mcx_book* b, int32_t product, int32_t roll_begin, int32_t roll_end, int32_t num_atom,
                            int32_t x_atom, double shift, double scale, const double* d_paths, int64_t n_paths, int64_t ld,
-                           double* d_W, int64_t ld_w, double* d_moments, int32_t flags, hipStream_t s, const char* who)
+                           double* d_W, int64_t ld_w, double* d_moments, int32_t flags, hipStream_t s, const char* who,
+                           int* grid_out = nullptr)          // grid_out: the caller sums the per-block partials (h->d_ws) itself
 {
     if (product < 0 || product >= b->n_products) MCX_FAIL(h, -2, "%s: product out of range", who);
     const DevProduct& pr = b->h_products[product];
@@ -627,6 +647,7 @@ static int lsm_step_launch(mcx_handle* h, const mcx_book* b, int32_t product, in
     if (ld < n_paths || ld_w < n_paths) MCX_FAIL(h, -2, "%s: leading dimension < n_paths", who);
     const int K = b->n_basis, S = pr.n_states;
     const int NM = (2 * K - 1) + S * K;
+    if (grid_out) *grid_out = 0;
     if (n_paths <= 0) { MCX_HIP(h, hipMemsetAsync(d_moments, 0, sizeof(double) * NM, s)); return 0; }
     const int grid = mcx_grid_for(n_paths, MCX_BLOCK, 4 * h->n_cu);
     if ((size_t)grid * NM * sizeof(double) > h->ws_bytes) MCX_FAIL(h, -2, "%s: workspace too small", who);
@@ -655,6 +676,7 @@ static int lsm_step_launch(mcx_handle* h, const mcx_book* b, int32_t product, in
     }
     if (rc != 0) MCX_FAIL(h, -3, "%s: unsupported (basis=%d, states=%d)", who, K, S);
     MCX_HIP(h, hipGetLastError());
+    if (grid_out) { *grid_out = grid; return 0; }
     hipLaunchKernelGGL(k3_finish, dim3(NM), dim3(MCX_BLOCK), 0, s, h->d_ws, NM, grid, d_moments);
     MCX_HIP(h, hipGetLastError());
     return 0;
@@ -708,14 +730,17 @@ extern "C" int mcx_lsm_run(mcx_handle* h, mcx_book* b, int32_t product, const mc
     int rc = 0;
     for (int d = 0; d < n_dates && rc == 0; ++d) {
         const mcx_lsm_date& q = h_dates[d];
+        const bool multi = h->comm && h->comm_ranks > 1;
+        int grid = 0;
         rc = lsm_step_launch(h, b, product, q.roll_begin, q.roll_end, q.num_atom, q.x_atom, q.shift, q.scale, d_paths, n_paths, ld, d_W, ld_w,
-                             d_mom, flags, s, "mcx_lsm_run");
+                             d_mom, flags, s, "mcx_lsm_run", multi ? nullptr : &grid);
         if (rc != 0) break;
-        if (h->comm && h->comm_ranks > 1) { rc = mcx_allreduce_f64(h, d_mom, NM, stream); if (rc != 0) break; }   // stream-ordered
+        if (multi) { rc = mcx_allreduce_f64(h, d_mom, NM, stream); if (rc != 0) break; }   // stream-ordered
         K3Solve sv;
         sv.shift = q.shift; sv.scale = q.scale; sv.x0 = q.x0; sv.off0 = q.coeff_off[0]; sv.off1 = q.coeff_off[1];
         sv.degenerate = q.degenerate; sv.K = K; sv.S = S; sv.date = d;
-        hipLaunchKernelGGL(k3_solve, dim3(1), dim3(64), 0, s, d_mom, sv, b->d_coeffs, d_tab, d_st);
+        if (!multi && grid > 0) hipLaunchKernelGGL(k3_finish_solve, dim3(1), dim3(1024), 0, s, h->d_ws, NM, grid, d_mom, sv, b->d_coeffs, d_tab, d_st);
+        else hipLaunchKernelGGL(k3_solve, dim3(1), dim3(64), 0, s, d_mom, sv, b->d_coeffs, d_tab, d_st);
         if (hipGetLastError() != hipSuccess) { h->err = "mcx_lsm_run: launch failed"; rc = -100; }
     }
     if (rc == 0 && (hipMemcpyAsync(h_coeffs, d_tab, tab_bytes, hipMemcpyDeviceToHost, s) != hipSuccess ||
