@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MCX_ABI_VERSION 5   /* 5: value polynomials (mcx_book_collapse_values), mcx_book_set_exercise_replay n_rows, mcx_sim_create rejects (model, scheme) pairs without a step map; 4: mcx_unsecured_desc.n_rows, mcx_lsm_step_batch w_len (host-side bounds of every row / offset a kernel reads); 3: mcx_rng_draws, mcx_comm_* (RCCL), interpolated collateral; 2: batched LSM, tangent-book kernels, bridge RNG */
+#define MCX_ABI_VERSION 6   /* 6: mcx_lsm_run_batch; 5: value polynomials (mcx_book_collapse_values), mcx_book_set_exercise_replay n_rows, mcx_sim_create rejects (model, scheme) pairs without a step map; 4: mcx_unsecured_desc.n_rows, mcx_lsm_step_batch w_len (host-side bounds of every row / offset a kernel reads); 3: mcx_rng_draws, mcx_comm_* (RCCL), interpolated collateral; 2: batched LSM, tangent-book kernels, bridge RNG */
 
 #define MCX_MAX_SLOTS   8    /* sub-models in one ModelConfig                                  */
 #define MCX_MAX_Z       8    /* total simulation dimension (correlated normals per sub-step)    */
@@ -497,6 +497,17 @@ int  mcx_lsm_step_batch_dev(mcx_handle* h, const mcx_book* book, const mcx_lsm_j
                             double* d_moments, int32_t flags, void* stream);
 int  mcx_lsm_solve_batch(mcx_handle* h, mcx_book* book, const mcx_lsm_solve_job* h_jobs, int32_t n_jobs, int32_t n_states,
                          const double* d_moments, int32_t* d_flag, void* stream);
+/* The whole product-batched backward induction in ONE call (replaces the Python loop of controller.py:289-383 over products and
+ * dates for books of thousands of products): step t runs the jobs [h_step_begin[t], h_step_begin[t+1]) of h_jobs / h_solve — all of
+ * h_step_states[t] exercise states — as mcx_lsm_step_batch_dev + mcx_lsm_solve_batch would (same kernels, same arithmetic per
+ * (product, date)); the job tables are uploaded once and the steps enqueued back to back.  With a communicator on the handle
+ * (mcx_comm_init) the moments of a step are all-reduced between roll and solve, stream-ordered; a rank without paths takes part with
+ * zero moments.  *h_flag != 0: some system was numerically singular (its coefficients were not written: repeat with
+ * mcx_lsm_step_batch and a host solver).  The call synchronises the stream. */
+int  mcx_lsm_run_batch(mcx_handle* h, mcx_book* book, const mcx_lsm_job* h_jobs, const mcx_lsm_solve_job* h_solve,
+                       const int32_t* h_step_begin, const int32_t* h_step_states, int32_t n_steps,
+                       const double* d_paths, int64_t n_paths, int64_t ld, double* d_W, int64_t ld_w, int64_t w_len,
+                       int32_t* h_flag, int32_t flags, void* stream);
 int  mcx_book_get_coeffs(mcx_handle* h, const mcx_book* book, int64_t offset, int64_t count, double* h_out, void* stream);
 /* coeffs[h_offsets[j] + q] = h_values[j * len + q], q < len, for n blocks in one call (the batched form of mcx_book_set_coeffs) */
 int  mcx_book_set_coeffs_batch(mcx_handle* h, mcx_book* book, const int64_t* h_offsets, int32_t n, int32_t len,

@@ -496,7 +496,7 @@ __global__ __launch_bounds__(MCX_BLOCK, MCX_LEAN_WAVES) void kf_lean(const Fused
 #undef FD
 
 // launch of one shape (paths per lane) of the kernel; returns the grid
-template <int NSLOT, int NZ, int SIG, int PPL>
+template <int NSLOT, int NZ, int SIG, int PPL, bool STREAM_ONLY = false>
 int launch_lean_shape(const FusedArgs& a, int n_cu, bool inject, bool simulate, hipStream_t s)
 {
     const int64_t tiles = (a.k1.n + MCX_BLOCK * PPL - 1) / (MCX_BLOCK * PPL);
@@ -520,11 +520,13 @@ int launch_lean_shape(const FusedArgs& a, int n_cu, bool inject, bool simulate, 
         const int64_t per = (tiles + resident - 1) / resident;  // equal number of tiles per block whenever the count divides
         return (int)((tiles + per - 1) / per);
     };
-    int grid;
+    int grid = -1;
     if (!simulate) {
         auto kern = kf_lean<NSLOT, NZ, false, SIG, PPL, false>;
         grid = sized(residency(kern));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(MCX_BLOCK), lds, s, a);
+    } else if constexpr (STREAM_ONLY) {
+        (void)inject;
     } else if (inject) {
         auto kern = kf_lean<NSLOT, NZ, true, SIG, PPL, true>;
         grid = sized(residency(kern));
@@ -563,6 +565,13 @@ void launch_lean(const FusedArgs& a, int n_cu, bool inject, bool simulate, hipSt
         *grid_out = launch_lean_shape<NSLOT, NZ, SIG, 1>(a, n_cu, inject, simulate, s);
         return;
     }
+#ifdef MCX_STREAM_PPL4
+    // the streaming pass carries no generator state: four paths per lane halve its scalar work per path (its bound)
+    if (PPL == 2 && !simulate && full_tiles >= (int64_t)8 * n_cu) {
+        *grid_out = launch_lean_shape<NSLOT, NZ, SIG, 4, true>(a, n_cu, inject, simulate, s);
+        return;
+    }
+#endif
     *grid_out = launch_lean_shape<NSLOT, NZ, SIG, PPL>(a, n_cu, inject, simulate, s);
 }
 

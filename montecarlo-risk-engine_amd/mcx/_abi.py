@@ -5,7 +5,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 SELECT_LOST = 1 << 44        # MCX_SELECT_LOST (mcx_select_bracket)
 MAX_SLOTS = 8
 MAX_Z = 8

@@ -22,7 +22,7 @@ _EXPORTS = [
     "mcx_sim_create", "mcx_sim_destroy", "mcx_generate_paths", "mcx_generate_paths_from_state", "mcx_rng_draws",
     "mcx_comm_unique_id", "mcx_comm_init", "mcx_comm_destroy", "mcx_allreduce_f64", "mcx_allgather_f64",
     "mcx_book_create", "mcx_book_destroy", "mcx_book_set_coeffs", "mcx_eval_book", "mcx_resolve_atoms",
-    "mcx_lsm_stats", "mcx_lsm_step", "mcx_lsm_run", "mcx_lsm_solve", "mcx_lsm_step_batch", "mcx_lsm_step_batch_dev", "mcx_lsm_solve_batch", "mcx_book_get_coeffs", "mcx_book_set_coeffs_batch", "mcx_book_set_bridge_rng", "mcx_book_set_exercise_replay",
+    "mcx_lsm_stats", "mcx_lsm_step", "mcx_lsm_run", "mcx_lsm_solve", "mcx_lsm_step_batch", "mcx_lsm_step_batch_dev", "mcx_lsm_solve_batch", "mcx_lsm_run_batch", "mcx_book_get_coeffs", "mcx_book_set_coeffs_batch", "mcx_book_set_bridge_rng", "mcx_book_set_exercise_replay",
     "mcx_fused_is_straight_line", "mcx_tangent_paths", "mcx_tangent_lsm", "mcx_tangent_lsm_step", "mcx_tangent_eval", "mcx_tangent_cva", "mcx_tangent_profiles", "mcx_tangent_pick",
     "mcx_box_muller", "mcx_tangent_european", "mcx_fused_create", "mcx_fused_destroy", "mcx_fused_num_records", "mcx_fused_run", "mcx_fused_eval_paths", "mcx_fused_run_device", "mcx_fused_eval_paths_device", "mcx_fused_set_timing", "mcx_fused_kernel_times",
     "mcx_value_poly_fit", "mcx_book_collapse_values", "mcx_book_value_poly_info", "mcx_rows_minmax",
@@ -511,6 +511,23 @@ class HipBackend:
         sj = np.ascontiguousarray(solve_jobs, dtype=_abi.LSM_SOLVE_JOB_DTYPE)
         self._check(self.lib.mcx_lsm_solve_batch(self.h, book.ptr, _abi.ptr(sj), C.c_int32(len(sj)), C.c_int32(n_states),
                                                  _vp(moments.data_ptr()), _vp(flag.data_ptr()), self._stream()), "mcx_lsm_solve_batch")
+
+    def lsm_run_batch(self, book, jobs: np.ndarray, solve_jobs: np.ndarray, step_begin: np.ndarray, step_states: np.ndarray,
+                      paths: torch.Tensor, W: torch.Tensor, ld_w: int, flags: int = 0) -> int:
+        """every (step, solve) pair of a product-batched backward induction in one call (mcx_lsm_run_batch): the tables of ALL steps,
+        step t = jobs[step_begin[t]:step_begin[t+1]] with step_states[t] exercise states -> singular-system flag"""
+        jobs = np.ascontiguousarray(jobs, dtype=_abi.LSM_JOB_DTYPE)
+        sj = np.ascontiguousarray(solve_jobs, dtype=_abi.LSM_SOLVE_JOB_DTYPE)
+        sb = np.ascontiguousarray(step_begin, dtype=np.int32)
+        ss = np.ascontiguousarray(step_states, dtype=np.int32)
+        assert len(sb) == len(ss) + 1 and len(jobs) == len(sj) == int(sb[-1])
+        n = paths.shape[2]
+        flag = C.c_int32(0)
+        self._check(self.lib.mcx_lsm_run_batch(
+            self.h, book.ptr, _abi.ptr(jobs), _abi.ptr(sj), _abi.ptr(sb), _abi.ptr(ss), C.c_int32(len(ss)), _vp(paths.data_ptr()),
+            C.c_int64(n), C.c_int64(n), _vp(W.data_ptr()), C.c_int64(ld_w), C.c_int64(W.numel()), C.byref(flag), C.c_int32(int(flags)),
+            self._stream()), "mcx_lsm_run_batch")
+        return int(flag.value)
 
     def book_get_coeffs(self, book) -> np.ndarray:
         out = np.zeros(len(book.plan.coeffs))

@@ -177,22 +177,37 @@ class SimulationController:
             out.append(b if counts[b] == 1 else f"{b}#{counts[b]}")
         return out
 
+    # The three per-product predicates are asked several times per product and run (compile, atom registration, regression, metric
+    # evaluation): answers are kept per product object until the next compilation (`_compile` / `invalidate` clear the memo)
+    def _memo(self, kind: str, product: Product, fn):
+        memo = self.__dict__.setdefault("_pred_memo", {})
+        key = (kind, id(product))
+        hit = memo.get(key)
+        if hit is None:
+            hit = memo[key] = bool(fn())
+        return hit
+
     def _can_use_analytic_exposure_for_product(self, product: Product) -> bool:
         ok = {MetricType.PV, MetricType.EPE, MetricType.PFE}
-        return all(m.metric_type in ok for m in self.risk_metrics.metrics) and product.supports_analytic_exposure(self.model)
+        return self._memo("analytic", product, lambda: all(m.metric_type in ok for m in self.risk_metrics.metrics)
+                          and product.supports_analytic_exposure(self.model))
 
     def _product_requires_regression(self, product: Product) -> bool:
-        if len(product.regression_timeline) > 0:
-            return True
-        if not self.risk_metrics.requires_exposure_profiles():
-            return False
-        return not self._can_use_analytic_exposure_for_product(product)
+        def ask():
+            if len(product.regression_timeline) > 0:
+                return True
+            if not self.risk_metrics.requires_exposure_profiles():
+                return False
+            return not self._can_use_analytic_exposure_for_product(product)
+        return self._memo("regression", product, ask)
 
     def _can_skip_monte_carlo_for_product(self, product: Product) -> bool:
-        if self.risk_metrics.requires_exposure_profiles():
-            return False
-        return all(m.metric_type == MetricType.PV and m.evaluation_type == Metric.EvaluationType.ANALYTICAL
-                   and product.supports_analytic_pv(self.model) for m in self.risk_metrics.metrics)
+        def ask():
+            if self.risk_metrics.requires_exposure_profiles():
+                return False
+            return all(m.metric_type == MetricType.PV and m.evaluation_type == Metric.EvaluationType.ANALYTICAL
+                       and product.supports_analytic_pv(self.model) for m in self.risk_metrics.metrics)
+        return self._memo("skip", product, ask)
 
     def _get_requests(self):
         reqs = defaultdict(set)
@@ -214,6 +229,7 @@ class SimulationController:
         sim_tl = [float(t) for t in self.simulation_timeline]
         K = self.regression_function.get_degree()
         comp = BookCompiler(self.model, sim_tl, K)
+        self._pred_memo = {}
         self._sched_atom_cache = {}          # atom ids belong to ONE compiler: a re-compilation must not reuse the previous ones
         E = len(self.exposure_timeline)
         expo_times = [float(t) for t in self.exposure_timeline]
@@ -233,7 +249,6 @@ class SimulationController:
             off += len(p.regression_timeline) * S * K
             self._extra_coeff_base.append(off)
             off += p._n_extra_coeffs()
-        comp.reserve_events(sum((E if want_expo else 0) + 2 * len(p.product_timeline) for p in self.products) + 16)
         expo_atom_cache: dict = {}
 
         def expo_atoms(asset):       # (numeraire, SPOT) atoms of every exposure date, once per asset
@@ -247,6 +262,7 @@ class SimulationController:
         expo_arr = np.asarray(expo_times, dtype=np.float64)
         num_atom_cache: dict = {}            # numeraire atom of a date: one lookup per distinct date instead of a request object per event
         expo_tmpl_cache: dict = {}
+        W_EV = _abi.EVENT_DTYPE.itemsize // 8
 
         def expo_template(asset):    # EVENT_DTYPE rows of the exposure events of one asset, product-independent fields filled
             hit = expo_tmpl_cache.get(asset)
@@ -261,77 +277,115 @@ class SimulationController:
                 expo_tmpl_cache[asset] = hit
             return hit
 
+        # Where the events of a product go depends on its payment dates alone (controller.py:401-426, 451-461): cashflow range
+        # [all cash events], then the evaluation range — the exposure events of ALL dates with the cash events spliced in where the
+        # reference evaluates them (before the first exposure date that is not earlier), cash events after the last exposure date at
+        # the end if cashflows are wanted.  Books of thousands of products have a handful of distinct payment schedules: the layout
+        # is computed once per schedule and the event array is filled class by class with array operations (phase B below); the
+        # per-product Python work (phase A) is the cash events alone.
+        layout_cache: dict = {}
+
+        def layout_of(pdates: tuple):
+            hit = layout_cache.get(pdates)
+            if hit is None:
+                n_cash = len(pdates)
+                if want_expo:
+                    first = np.searchsorted(expo_arr, np.asarray(pdates, dtype=np.float64), side="left") if n_cash else np.zeros(0, dtype=np.int64)
+                    n_sp = int(np.count_nonzero(first < E))                          # (payment dates ascend: the spliced events come first)
+                    expo_dest = np.arange(E) + np.searchsorted(first[:n_sp], np.arange(E), side="right")
+                    cash_dest = first[:n_sp] + np.arange(n_sp)
+                    n_tail = n_cash - n_sp if want_cfs else 0
+                    cash_dest = np.concatenate([cash_dest, E + n_sp + np.arange(n_tail)]).astype(np.int64)
+                    hit = (expo_dest.astype(np.int64), cash_dest, E + n_sp + n_tail)
+                else:
+                    hit = (None, np.arange(n_cash, dtype=np.int64), n_cash)
+                layout_cache[pdates] = hit
+            return hit
+
+        # ---- phase A: per product — cash events (atoms / terms are created in the order the reference visits them) ----------------
+        n_prod = len(self.products)
+        cash_rows: list = []
+        cash_start = np.zeros(n_prod + 1, dtype=np.int64)
+        ev_len = np.zeros(n_prod, dtype=np.int64)
+        n_states = np.zeros(n_prod, dtype=np.int32)
+        init_state = np.zeros(n_prod, dtype=np.int32)
+        cash_classes: dict = {}              # layout -> products
+        expo_classes: dict = {}              # (asset, analytic, n_states, layout) -> products
+        bs_in: dict = {}                     # analytic exposure inputs of a product
         for p_i, p in enumerate(self.products):
             S = p.get_num_states()
+            n_states[p_i], init_state[p_i] = S, p.get_initial_state()
             skip = self._can_skip_monte_carlo_for_product(p)
             comp.current_product = p_i
             cash = [] if skip else p._cash_events(comp)
-            pdates = p.product_timeline.tolist()
+            pdates = tuple(p.product_timeline.tolist())
             assert skip or len(cash) == len(pdates)
-
-            emitted: dict = {}                 # a cash event appears twice (cashflow range + evaluation range): built once
-
-            def emit_cash(ce):
-                row = emitted.get(id(ce))
-                if row is None:
-                    nt = ce.time if ce.num_time is None else ce.num_time
-                    num = num_atom_cache.get(nt)
-                    if num is None:
-                        num = num_atom_cache[nt] = comp.atom(AtomicRequest(AtomicRequestType.NUMERAIRE, nt), "numeraire", nt)
-                    has_x = ce.kind == _abi.EV_EXERCISE or ce.x_time is not None or ce.x_asset is not None       # (an asset id may be None)
-                    x = comp.atom(AtomicRequest(AtomicRequestType.SPOT), ce.x_asset, ce.time if ce.x_time is None else ce.x_time) if has_x else -1
-                    co = -1 if ce.reg_idx is None else self._reg_coeff_base[p_i] + ce.reg_idx * S * K
-                    if ce.coeff_params:
-                        co = self._extra_coeff_base[p_i]
-                        for k_, v_ in enumerate(ce.coeff_params):
-                            comp.coeff_init[co + k_] = float(v_)
-                    tr = comp.add_terms(ce.terms)
-                    row = emitted[id(ce)] = (ce.kind, comp.tidx(ce.time), num, x, tr[0], tr[1], co, -1, float(ce.strike), float(ce.sign), tuple(ce.aux))
-                return comp.add_event_row(row)
-
-            cf_begin = comp.n_events
             for ce in cash:
-                emit_cash(ce)
-            cf_end = comp.n_events
-            ev_begin = comp.n_events
-            if not skip:
-                t_start = 0
-                if want_expo:
-                    # exposure events of ALL dates as array blocks, the product's cashflow events spliced in where the reference
-                    # evaluates them: before the first exposure date that is not earlier (controller.py:417-426)
-                    analytic = self._can_use_analytic_exposure_for_product(p)
-                    tmpl = expo_template(p.asset_ids[0])
-                    blk = tmpl.copy()
-                    if analytic:
-                        _s, sig_p, rate_p = p._bs_inputs(self.model)
-                        blk["kind"] = _abi.EV_EXPO_BS
-                        blk["coeff_off"] = -1
-                        blk["strike"], blk["sign"] = p._K, p._sign()
-                        blk["aux"][:, 0], blk["aux"][:, 1] = sig_p, rate_p
-                        blk["aux"][:, 2] = float(p.exercise_date[0]) - expo_arr
-                    else:
-                        blk["kind"] = _abi.EV_EXPO_POLY
-                        blk["coeff_off"] = self._expo_coeff_base[p_i] + np.arange(E, dtype=np.int64) * (S * K)
-                    first = np.searchsorted(expo_arr, np.asarray(pdates), side="left") if pdates else np.zeros(0, dtype=np.int64)
-                    pos = 0
-                    for c_i, f in enumerate(first):
-                        if f >= E:
-                            break                       # paid after the last exposure date: emitted below if cashflows are wanted
-                        if f > pos:
-                            comp.add_event_block(blk[pos:f])
-                            pos = int(f)
-                        emit_cash(cash[c_i])
-                        t_start = c_i + 1
-                    comp.add_event_block(blk[pos:])
-                if want_cfs or not want_expo:
-                    while t_start < len(pdates):                                          # controller.py:401-410, 451-461
-                        emit_cash(cash[t_start])
-                        t_start += 1
-                self._mc_products.append(p_i)
-                self._mc_set.add(p_i)
-            ev_end = comp.n_events
-            prods[p_i] = (ev_begin, ev_end, cf_begin, cf_end, self.product_to_netting_set_idx[p_i],
-                          p.get_initial_state(), S, 0)
+                nt = ce.time if ce.num_time is None else ce.num_time
+                num = num_atom_cache.get(nt)
+                if num is None:
+                    num = num_atom_cache[nt] = comp.atom(AtomicRequest(AtomicRequestType.NUMERAIRE, nt), "numeraire", nt)
+                has_x = ce.kind == _abi.EV_EXERCISE or ce.x_time is not None or ce.x_asset is not None       # (an asset id may be None)
+                x = comp.atom(AtomicRequest(AtomicRequestType.SPOT), ce.x_asset, ce.time if ce.x_time is None else ce.x_time) if has_x else -1
+                co = -1 if ce.reg_idx is None else self._reg_coeff_base[p_i] + ce.reg_idx * S * K
+                if ce.coeff_params:
+                    co = self._extra_coeff_base[p_i]
+                    for k_, v_ in enumerate(ce.coeff_params):
+                        comp.coeff_init[co + k_] = float(v_)
+                tr = comp.add_terms(ce.terms)
+                cash_rows.append((ce.kind, comp.tidx(ce.time), num, x, tr[0], tr[1], co, -1, float(ce.strike), float(ce.sign), tuple(ce.aux)))
+            cash_start[p_i + 1] = len(cash_rows)
+            if skip:
+                continue
+            lay = layout_of(pdates)
+            ev_len[p_i] = lay[2]
+            cash_classes.setdefault(id(lay), (lay, []))[1].append(p_i)
+            if want_expo:
+                analytic = self._can_use_analytic_exposure_for_product(p)
+                asset = p.asset_ids[0]
+                expo_template(asset)                                                  # (creates the asset's exposure atoms HERE, as before)
+                expo_classes.setdefault((asset, analytic, S, id(lay)), (lay, []))[1].append(p_i)
+                if analytic:
+                    _s, sig_p, rate_p = p._bs_inputs(self.model)
+                    bs_in[p_i] = (float(p._K), float(p._sign()), float(sig_p), float(rate_p), float(p.exercise_date[0]))
+            self._mc_products.append(p_i)
+            self._mc_set.add(p_i)
+        # ---- phase B: the event array, class by class ----------------------------------------------------------------------------
+        n_cash = np.diff(cash_start)
+        cf_begin = np.concatenate([[0], np.cumsum(n_cash + ev_len)])[:-1]
+        ev_begin = cf_begin + n_cash
+        n_ev = int((n_cash + ev_len).sum())
+        comp.reserve_events(n_ev)
+        raw = comp._ev_raw
+        crow = (np.array(cash_rows, dtype=_abi.EVENT_DTYPE) if cash_rows else np.zeros(0, dtype=_abi.EVENT_DTYPE)).view(np.float64).reshape(-1, W_EV)
+        if len(crow):                                                                 # cashflow ranges: every product's cash events in order
+            raw[np.repeat(cf_begin - cash_start[:-1], n_cash) + np.arange(len(crow))] = crow
+        for lay, members in cash_classes.values():                                    # the cash events inside the evaluation ranges
+            cd = lay[1]
+            if len(cd):
+                m = np.asarray(members)
+                raw[(ev_begin[m][:, None] + cd[None, :]).reshape(-1)] = crow[(cash_start[m][:, None] + np.arange(len(cd))[None, :]).reshape(-1)]
+        eb = np.asarray(self._expo_coeff_base, dtype=np.int64)
+        for (asset, analytic, S, _l), (lay, members) in expo_classes.items():         # the exposure events
+            m = np.asarray(members)
+            blk_raw = np.broadcast_to(expo_template(asset).view(np.float64).reshape(1, E, W_EV), (len(m), E, W_EV)).copy()
+            blk = blk_raw.reshape(-1).view(_abi.EVENT_DTYPE).reshape(len(m), E)
+            if analytic:
+                par = np.array([bs_in[q] for q in members])                          # [m][strike, sign, sigma, rate, exercise date]
+                blk["kind"] = _abi.EV_EXPO_BS
+                blk["coeff_off"] = -1
+                blk["strike"], blk["sign"] = par[:, 0:1], par[:, 1:2]
+                blk["aux"][:, :, 0], blk["aux"][:, :, 1] = par[:, 2:3], par[:, 3:4]
+                blk["aux"][:, :, 2] = par[:, 4:5] - expo_arr[None, :]
+            else:
+                blk["kind"] = _abi.EV_EXPO_POLY
+                blk["coeff_off"] = eb[m][:, None] + np.arange(E, dtype=np.int64)[None, :] * (S * K)
+            raw[(ev_begin[m][:, None] + lay[0][None, :]).reshape(-1)] = blk_raw.reshape(-1, W_EV)
+        comp.n_events = n_ev
+        prods["ev_begin"], prods["ev_end"] = ev_begin, ev_begin + ev_len
+        prods["cf_begin"], prods["cf_end"] = cf_begin, ev_begin
+        prods["netting_set"] = [self.product_to_netting_set_idx[q] for q in range(n_prod)]
+        prods["init_state"], prods["n_states"] = init_state, n_states
         # CVA survival atoms (cva_metric.py:23-46)
         self._cva_atoms = {}
         mt = [float(t) for t in self.metric_exposure_timeline]
@@ -534,55 +588,80 @@ class SimulationController:
                             expo_idx=[-1 if s[4] is None else s[4] for s in sched],
                             num=[a_[0] for a_ in atoms], x=[a_[1] for a_ in atoms], xmin=lo, deg=deg,
                             shift=np.where(deg, lo, 0.5 * (lo + hi)), scale=np.where(deg, 1.0, 2.0 / np.where(deg, 1.0, hi - lo))))
-        max_len = max(cl["L"] for cl in cls)
-        # solves on the device when the backend has them: (step, all-reduce, solve) enqueued back to back for all ~600 steps of a
-        # big book, one read-back of the coefficient array at the end; a singular system anywhere repeats the induction with
-        # the host solver (which falls back to lstsq)
+        # the job / solve tables of ALL steps at once.  Step order as the reference walks it (one date further back per step, the
+        # products of one exercise-state count per launch): step (r, S) holds, class by class, the members of every class with S
+        # states whose schedule is longer than r.  Destination rows by cumulative sums over a [class][r] matrix, fields by
+        # broadcast assignment per class — no Python iteration per (product, date) or per step.
+        n_cls, max_len = len(cls), max(cl["L"] for cl in cls)
+        L_c = np.array([cl["L"] for cl in cls]); S_c = np.array([cl["S"] for cl in cls]); n_c = np.array([len(cl["members"]) for cl in cls])
+        S_vals = sorted(set(S_c.tolist()))
+        active = np.arange(max_len)[None, :] < L_c[:, None]
+        within = np.zeros((n_cls, max_len), dtype=np.int64)
+        size = np.zeros((max_len, len(S_vals)), dtype=np.int64)
+        for k_, S in enumerate(S_vals):
+            sz = n_c[:, None] * (active & (S_c == S)[:, None])
+            within += np.where((S_c == S)[:, None], np.cumsum(sz, axis=0) - sz, 0)
+            size[:, k_] = sz.sum(axis=0)
+        flat = size.reshape(-1)
+        start = np.concatenate([[0], np.cumsum(flat)])
+        keep = flat > 0
+        step_states = np.tile(np.array(S_vals, dtype=np.int32), max_len)[keep]
+        step_begin = np.concatenate([[0], np.cumsum(flat[keep])]).astype(np.int32)
+        n_jobs = int(start[-1])
+        jt = np.zeros(n_jobs, dtype=_abi.LSM_JOB_DTYPE)
+        sj = np.zeros(n_jobs, dtype=_abi.LSM_SOLVE_JOB_DTYPE)
+        sj_off = sj["coeff_off"]
+        for c_, cl in enumerate(cls):
+            S, L, n_m = cl["S"], cl["L"], int(n_c[c_])
+            d0 = start[np.arange(L) * len(S_vals) + S_vals.index(S)] + within[c_, :L]
+            dest = (d0[:, None] + np.arange(n_m)[None, :]).reshape(-1)
+            col = lambda v, dt=None: np.repeat(np.asarray(v, dtype=dt), n_m)            # one value per step -> every member
+            row = lambda v: np.tile(v, L)                                              # one value per member -> every step
+            jt["product"][dest], jt["w_offset"][dest] = row(cl["p_i"]), row(cl["w_off"])
+            jt["roll_begin"][dest], jt["roll_end"][dest] = col(cl["r0"]), col(cl["r1"])
+            jt["num_atom"][dest], jt["x_atom"][dest] = col(cl["num"]), col(cl["x"])
+            jt["shift"][dest] = sj["shift"][dest] = col(cl["shift"])
+            jt["scale"][dest] = sj["scale"][dest] = col(cl["scale"])
+            sj["x0"][dest], sj["degenerate"][dest] = col(cl["xmin"]), col(cl["deg"], np.int32)
+            pr, ex = np.asarray(cl["prod_idx"], dtype=np.int64), np.asarray(cl["expo_idx"], dtype=np.int64)
+            t_prod = np.where(pr[:, None] >= 0, cl["reg_base"][None, :] + pr[:, None] * (S * K), -1)
+            t_expo = np.where(ex[:, None] >= 0, cl["expo_base"][None, :] + ex[:, None] * (S * K), -1)
+            has_p = np.broadcast_to(pr[:, None] >= 0, t_prod.shape)                   # at most two targets per system, the product block first
+            sj_off[dest, 0] = np.where(has_p, t_prod, t_expo).reshape(-1)
+            sj_off[dest, 1] = np.where(has_p, t_expo, -1).reshape(-1)
+        # solves on the device when the backend has them; a singular system anywhere repeats the induction with the host solver
+        # (which falls back to lstsq)
         on_device = hasattr(be, "lsm_solve_batch") and not getattr(self, "_lsm_host_solves", False)
-        flag = be.zeros(1, dtype=torch.int32) if on_device else None
-        for r in range(max_len):
-            for S in sorted({cl["S"] for cl in cls if cl["L"] > r}):
-                blocks, xmin_b, deg_b, t_rows, t_offs, row0 = [], [], [], [], [], 0
-                for cl in cls:
-                    if cl["S"] != S or cl["L"] <= r:
-                        continue
-                    n_m = len(cl["members"])
-                    arr = np.zeros(n_m, dtype=_abi.LSM_JOB_DTYPE)
-                    arr["product"], arr["w_offset"] = cl["p_i"], cl["w_off"]
-                    arr["roll_begin"], arr["roll_end"], arr["num_atom"], arr["x_atom"] = cl["r0"][r], cl["r1"][r], cl["num"][r], cl["x"][r]
-                    arr["shift"], arr["scale"] = cl["shift"][r], cl["scale"][r]
-                    blocks.append(arr)
-                    xmin_b.append(np.full(n_m, cl["xmin"][r])); deg_b.append(np.full(n_m, cl["deg"][r]))
-                    rows = row0 + np.arange(n_m)
-                    if cl["prod_idx"][r] >= 0:
-                        t_rows.append(rows); t_offs.append(cl["reg_base"] + cl["prod_idx"][r] * S * K)
-                    if cl["expo_idx"][r] >= 0:
-                        t_rows.append(rows); t_offs.append(cl["expo_base"] + cl["expo_idx"][r] * S * K)
-                    row0 += n_m
-                arr = np.concatenate(blocks)
+        singular = 0
+        if on_device and shard.world == 1 and hasattr(be, "lsm_run_batch") and getattr(self, "lsm_one_call", True):
+            # one GPU: every (step, solve) pair enqueued by ONE library call (mcx_lsm_run_batch), tables uploaded once
+            singular = be.lsm_run_batch(self.book, jt, sj, step_begin, step_states, paths, W, n_local, flags=lsm_flags)
+        else:
+            flag = be.zeros(1, dtype=torch.int32) if on_device else None
+            for t_ in range(len(step_states)):
+                j0, j1, S = int(step_begin[t_]), int(step_begin[t_ + 1]), int(step_states[t_])
+                arr, sv = jt[j0:j1], sj[j0:j1]
                 if on_device:
-                    sj = np.zeros(len(arr), dtype=_abi.LSM_SOLVE_JOB_DTYPE)
-                    sj["shift"], sj["scale"], sj["x0"], sj["degenerate"] = arr["shift"], arr["scale"], np.concatenate(xmin_b), np.concatenate(deg_b)
-                    sj["coeff_off"][:] = -1
-                    filled = np.zeros(len(arr), dtype=np.int64)
-                    for rows, offs in zip(t_rows, t_offs):                    # at most two targets per system: product / exposure block
-                        sj["coeff_off"][rows, filled[rows]] = offs
-                        filled[rows] += 1
+                    # several GPUs under torch.distributed: (step, all-reduce, solve) enqueued back to back, stream-ordered
                     mom = be.lsm_step_batch_dev(self.book, arr, S, paths, W, n_local, flags=lsm_flags)
                     shard.all_reduce_(mom)
-                    be.lsm_solve_batch(self.book, sj, S, mom, flag)
+                    be.lsm_solve_batch(self.book, sv, S, mom, flag)
                     continue
                 mom = be.lsm_step_batch(self.book, arr, S, paths, W, n_local, flags=lsm_flags)
                 mom = shard.all_reduce_np(mom)
-                coeffs = solve_normal_equations_batch(mom, K, S, arr["shift"], arr["scale"], np.concatenate(deg_b),
-                                                      np.concatenate(xmin_b)).reshape(len(arr), S * K)
-                if t_rows:
-                    rows, offs = np.concatenate(t_rows), np.concatenate(t_offs).astype(np.int64)
+                coeffs = solve_normal_equations_batch(mom, K, S, arr["shift"], arr["scale"], sv["degenerate"].astype(bool),
+                                                      sv["x0"]).reshape(len(arr), S * K)
+                tgt = sv["coeff_off"]
+                rows = np.concatenate([np.nonzero(tgt[:, w] >= 0)[0] for w in (0, 1)])
+                if len(rows):
+                    offs = np.concatenate([tgt[tgt[:, w] >= 0, w] for w in (0, 1)]).astype(np.int64)
                     vals = coeffs[rows]
                     be.book_set_coeffs_batch(self.book, offs, vals)
                     mirror[offs[:, None] + np.arange(S * K)[None, :]] = vals
+            if on_device:
+                singular = int(flag.cpu()[0])
         if on_device:
-            if int(flag.cpu()[0]) != 0:
+            if singular != 0:
                 self._lsm_host_solves = True
                 try:
                     be.book_reset_coeffs(self.book, self._coeffs_at_upload)
@@ -592,14 +671,15 @@ class SimulationController:
             mirror = be.book_get_coeffs(self.book)
             self.book.plan.coeffs[:] = mirror                                 # (the host image of the uploaded book follows)
         E = len(self.exposure_timeline)
-        for p_i, p, _, _ in jobs:
-            S = p.get_num_states()
+        mt = torch.from_numpy(mirror)                                 # the products' coefficient tensors are views of this one image
+        for j, (p_i, p, _, _) in enumerate(jobs):
+            S = S_of[j]
             b0 = self._expo_coeff_base[p_i]
-            self.regression_coeffs[p_i] = torch.from_numpy(mirror[b0:b0 + E * S * K].reshape(E, S, K).copy())
+            self.regression_coeffs[p_i] = mt[b0:b0 + E * S * K].view(E, S, K)
             R = len(p.regression_timeline)
             if R:
                 b1 = self._reg_coeff_base[p_i]
-                p.regression_coeffs = torch.from_numpy(mirror[b1:b1 + R * S * K].reshape(R, S, K).copy())
+                p.regression_coeffs = mt[b1:b1 + R * S * K].view(R, S, K)
 
     def _set_bridge_rng(self, seed: int, path_offset: int, inject_key: str):
         """Brownian-bridge barrier events draw their uniforms inside the book / LSM kernels (mcx_book_set_bridge_rng)"""
@@ -1099,6 +1179,7 @@ class SimulationController:
     def invalidate(self):
         """forget the compiled descriptors / uploaded book (after mutating a product, a metric or a netting set)"""
         self._compiled_key = None
+        self._pred_memo = {}
 
     def _compile_all(self):
         """objects -> descriptors, LSM atoms registered before the plan is frozen and uploaded.  A controller that is run again

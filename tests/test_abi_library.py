@@ -19,7 +19,7 @@ def test_header_symbols_are_exported():
     assert len(syms) >= 19
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/mcx.h but not exported"
-    assert lib.mcx_abi_version() == 5
+    assert lib.mcx_abi_version() == 6
     assert set(_native._EXPORTS) == set(syms)
 
 

@@ -424,6 +424,13 @@ def test_large_book_product_batched_kernels_match_oracle(hip, oracle):
     # the same book with the host solver behind the batched steps (the fallback a singular system takes): same coefficients as the
     # device solves of the run above
     dev = [c.numpy().copy() for c in sc.regression_coeffs]
+    # ... and with the (step, solve) pairs enqueued one by one from Python (the several-GPU branch) instead of by mcx_lsm_run_batch:
+    # the same kernels on the same tables, bit for bit
+    sc.lsm_one_call = False
+    sc._compiled_key = None
+    sc.run_simulation()
+    for a, b in zip(dev, [c.numpy() for c in sc.regression_coeffs]):
+        assert np.array_equal(a, b)
     sc._lsm_host_solves = True
     sc._compiled_key = None
     sc.run_simulation()

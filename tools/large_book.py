@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--paths", type=int, default=1000)
     ap.add_argument("--exposure-points", type=int, default=80)
     ap.add_argument("--repeat", type=int, default=2)
+    ap.add_argument("--profile", action="store_true", help="cProfile the last repetition's run_simulation (top functions to stderr)")
     args = ap.parse_args()
     from mcx import _native
     be = _native.HipBackend(0)
@@ -110,7 +111,13 @@ def main():
         sc = SimulationController([ns], model, RiskMetrics([cva], exposure_timeline=tl), args.paths, args.paths, 1,
                                   SimulationScheme.EULER, backend=be)
         t1 = time.perf_counter()
-        res = sc.run_simulation()
+        if args.profile and rep == args.repeat - 1:
+            import cProfile, pstats
+            pr = cProfile.Profile(); pr.enable()
+            res = sc.run_simulation()
+            pr.disable(); pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(30)
+        else:
+            res = sc.run_simulation()
         be.synchronize()
         t2 = time.perf_counter()
         out = dict(products=len(products), counts=counts, paths=args.paths, exposure_points=args.exposure_points,
