@@ -183,7 +183,7 @@ def main():
     if fused_obj is None:
         names = ["unfused"]
     if any(n != "fused" for n in names):
-        paths_buf = be.empty(T, D, n_local)
+        paths_buf = be.empty_paths(T, D, n_local)
 
     def set_plan(name):
         sc._fused = None if name == "unfused" else fused_obj

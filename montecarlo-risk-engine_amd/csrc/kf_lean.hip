@@ -442,7 +442,6 @@ __global__ __launch_bounds__(MCX_BLOCK, MCX_LEAN_WAVES) void kf_lean(const Fused
             if (st >= 0) lean_date<NSLOT, SIG, PPL, true>(st, i, live, first_tile, lds, reg, cfs, cva, est, etab);
         }
         } else {
-            double nxt[PPL][NREG];
             auto load_row = [&](int t, double (&dst)[PPL][NREG]) {
                 const auto& k = kargs_region(0).k1;
                 const int D = k.n_state;
@@ -457,17 +456,20 @@ __global__ __launch_bounds__(MCX_BLOCK, MCX_LEAN_WAVES) void kf_lean(const Fused
                     }
             };
             const int n_dates = kargs_region(0).n_dates;
-            double nx2[PPL][NREG];                     // two dates in flight: the pass is a pure stream, latency is hidden by depth
-            load_row(0, nxt);
-            load_row(n_dates > 1 ? 1 : 0, nx2);
+            // the pass is a pure stream: two state buffers, the date loop unrolled by two so that each buffer is consumed where its
+            // loads landed (a single call site with a rotating third buffer cost 32 register copies per path and date — a fifth of the
+            // VALU work of the pass); the loads of date t+2 go out as soon as date t is done and have the program of date t+1 to land
+            double bufb[PPL][NREG];
+            load_row(0, reg);
+            load_row(n_dates > 1 ? 1 : 0, bufb);
 #pragma unroll 1
-            for (int t = 0; t < n_dates; ++t) {
-#pragma unroll
-                for (int q = 0; q < PPL; ++q)
-#pragma unroll
-                    for (int r = 0; r < NREG; ++r) { reg[q][r] = nxt[q][r]; nxt[q][r] = nx2[q][r]; }
-                if (t + 2 < n_dates) load_row(t + 2, nx2);            // the state of date t+2 streams in while this date's program runs
+            for (int t = 0; t < n_dates; t += 2) {
                 lean_date<NSLOT, SIG, PPL, false>(t, i, live, first_tile, lds, reg, cfs, cva, est, etab);
+                if (t + 2 < n_dates) load_row(t + 2, reg);
+                if (t + 1 < n_dates) {
+                    lean_date<NSLOT, SIG, PPL, false>(t + 1, i, live, first_tile, lds, bufb, cfs, cva, est, etab);
+                    if (t + 3 < n_dates) load_row(t + 3, bufb);
+                }
             }
         }
         {
@@ -496,7 +498,7 @@ __global__ __launch_bounds__(MCX_BLOCK, MCX_LEAN_WAVES) void kf_lean(const Fused
 #undef FD
 
 // launch of one shape (paths per lane) of the kernel; returns the grid
-template <int NSLOT, int NZ, int SIG, int PPL, bool STREAM_ONLY = false>
+template <int NSLOT, int NZ, int SIG, int PPL>
 int launch_lean_shape(const FusedArgs& a, int n_cu, bool inject, bool simulate, hipStream_t s)
 {
     const int64_t tiles = (a.k1.n + MCX_BLOCK * PPL - 1) / (MCX_BLOCK * PPL);
@@ -520,13 +522,11 @@ int launch_lean_shape(const FusedArgs& a, int n_cu, bool inject, bool simulate, 
         const int64_t per = (tiles + resident - 1) / resident;  // equal number of tiles per block whenever the count divides
         return (int)((tiles + per - 1) / per);
     };
-    int grid = -1;
+    int grid;
     if (!simulate) {
         auto kern = kf_lean<NSLOT, NZ, false, SIG, PPL, false>;
         grid = sized(residency(kern));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(MCX_BLOCK), lds, s, a);
-    } else if constexpr (STREAM_ONLY) {
-        (void)inject;
     } else if (inject) {
         auto kern = kf_lean<NSLOT, NZ, true, SIG, PPL, true>;
         grid = sized(residency(kern));
@@ -565,13 +565,6 @@ void launch_lean(const FusedArgs& a, int n_cu, bool inject, bool simulate, hipSt
         *grid_out = launch_lean_shape<NSLOT, NZ, SIG, 1>(a, n_cu, inject, simulate, s);
         return;
     }
-#ifdef MCX_STREAM_PPL4
-    // the streaming pass carries no generator state: four paths per lane halve its scalar work per path (its bound)
-    if (PPL == 2 && !simulate && full_tiles >= (int64_t)8 * n_cu) {
-        *grid_out = launch_lean_shape<NSLOT, NZ, SIG, 4, true>(a, n_cu, inject, simulate, s);
-        return;
-    }
-#endif
     *grid_out = launch_lean_shape<NSLOT, NZ, SIG, PPL>(a, n_cu, inject, simulate, s);
 }
 

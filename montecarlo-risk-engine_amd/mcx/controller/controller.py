@@ -662,6 +662,7 @@ class SimulationController:
                 singular = int(flag.cpu()[0])
         if on_device:
             if singular != 0:
+                self.lsm_singular_retries = getattr(self, "lsm_singular_retries", 0) + 1
                 self._lsm_host_solves = True
                 try:
                     be.book_reset_coeffs(self.book, self._coeffs_at_upload)
@@ -988,7 +989,9 @@ class SimulationController:
         t = bufs.get(name)
         if t is None or tuple(t.shape) != tuple(shape):
             bufs[name] = None
-            t = bufs[name] = self.backend.empty(*shape)
+            # (the path / exposure / cashflow matrices of a run without injected draws take the backend's padded leading dimension)
+            padded = name in ("paths", "expo", "cfs") and hasattr(self.backend, "empty_padded") and not self._inject
+            t = bufs[name] = self.backend.empty_padded(*shape) if padded else self.backend.empty(*shape)
         return t
 
     def release_device_buffers(self):

@@ -43,8 +43,14 @@ class BlackScholesMulti(Model):
         return self.correlation_matrix
 
     def _get_covariance_matrix(self, delta_t) -> torch.Tensor:
-        S = torch.diag(self.get_volatility().detach())
-        return S @ self.correlation_matrix @ S * float(delta_t)               # black_scholes_multi.py:56-61
+        # S C S is the same for every step length: kept per volatility vector (an analytical-scheme timeline of a large book asks for
+        # the factor of ~400 distinct step lengths; torch.diag + two products per call were 0.1 s of its planning)
+        vols = tuple(self._pf(self.num_assets + i) for i in range(self.num_assets))
+        hit = self.__dict__.get("_scs")
+        if hit is None or hit[0] != vols:
+            S = torch.diag(self.get_volatility().detach())
+            hit = self.__dict__["_scs"] = (vols, S @ self.correlation_matrix @ S)
+        return hit[1] * float(delta_t)                                       # black_scholes_multi.py:56-61
 
     # ---- native hooks -------------------------------------------------------------------------------------------
     def _rate(self) -> float:

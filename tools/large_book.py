@@ -1,11 +1,17 @@
 #!/usr/bin/env python3
-"""Large mixed netting set CVA: the book of the reference's own performance script
-(tests/exposure_tests/cva_perfprmance_large_netting_set.py:69-148 with pv_tests/pv_performance_large_netting_set.py:86-233)
-— Europeans, binaries, baskets, Asians, barriers, Americans, FlexiCalls on a 4-asset BlackScholesMulti + CIR++ credit,
-10-day MPoR collateral, 80 exposure dates, 1000 + 1000 paths, one Euler step per date — WITHOUT the gas-storage products
-(out of scope).  Prints products/s like the reference script.
+"""Large mixed netting sets: the books of the reference's three performance scripts — Europeans, binaries,
+baskets, Asians, barriers, Americans, FlexiCalls on a 4-asset BlackScholesMulti (book builder: pv_tests/
+pv_performance_large_netting_set.py:86-233), WITHOUT the gas-storage products (out of scope), 1000 + 1000 paths:
 
-    python tools/large_book.py [--scale 1.0] [--paths 1000]"""
+  --book cva  tests/exposure_tests/cva_perfprmance_large_netting_set.py:69-148 — 4,990 products, + CIR++ credit, 10-day MPoR
+              collateral, CVA on 80 exposure dates, one Euler step per date
+  --book ee   tests/exposure_tests/ee_performance_large_netting_set.py:17-122 — 4,990 products, EPE + PFE(0.95) on 80 dates,
+              analytical scheme, unsecured
+  --book pv   tests/pv_tests/pv_performance_large_netting_set.py:266-316 — 49,900 products, Monte-Carlo PV, analytical scheme
+
+Prints products/s of run_simulation() like the reference scripts.
+
+    python tools/large_book.py [--book cva] [--scale 1.0] [--paths 1000]"""
 import argparse
 import json
 import os
@@ -20,6 +26,9 @@ sys.path.insert(0, os.path.join(ROOT, "montecarlo-risk-engine_amd"))
 from mcx.common.enums import SimulationScheme                                          # noqa: E402
 from mcx.controller.controller import SimulationController                            # noqa: E402
 from mcx.metrics.cva_metric import CVAMetric                                           # noqa: E402
+from mcx.metrics.epe_metric import EPEMetric                                           # noqa: E402
+from mcx.metrics.pfe_metric import PFEMetric                                           # noqa: E402
+from mcx.metrics.pv_metric import PVMetric                                             # noqa: E402
 from mcx.metrics.risk_metrics import RiskMetrics                                       # noqa: E402
 from mcx.models.black_scholes_multi import BlackScholesMulti                           # noqa: E402
 from mcx.models.cirpp import CIRPPModel                                                # noqa: E402
@@ -91,25 +100,32 @@ def main():
     ap.add_argument("--paths", type=int, default=1000)
     ap.add_argument("--exposure-points", type=int, default=80)
     ap.add_argument("--repeat", type=int, default=2)
+    ap.add_argument("--book", choices=("cva", "ee", "pv"), default="cva")
     ap.add_argument("--profile", action="store_true", help="cProfile the last repetition's run_simulation (top functions to stderr)")
     args = ap.parse_args()
     from mcx import _native
     be = _native.HipBackend(0)
     ids = [f"asset_{k}" for k in range(4)]
-    counts = [max(1, int(round(c * args.scale))) for c in (3940, 100, 100, 200, 400, 180, 70)]
+    mult = 10 if args.book == "pv" else 1
+    counts = [max(1, int(round(c * mult * args.scale))) for c in (3940, 100, 100, 200, 400, 180, 70)]
     for rep in range(args.repeat):
         corr = np.full((4, 4), 0.35); np.fill_diagonal(corr, 1.0)
         market = BlackScholesMulti(0.0, 0.03, ids, [95.0 + 7.5 * k for k in range(4)], [0.18 + 0.03 * k for k in range(4)], corr)
-        credit = CIRPPModel(0.0, CP, HAZARDS, kappa=0.10, theta=0.01, volatility=0.02, y0=0.0001, deterministic=False)
-        model = ModelConfig([market, credit], inter_asset_correlation_matrix=[np.full((4, 1), 0.2)])
         products = build_mixed_book(ids, *counts)
         horizon = max(float(p.modeling_timeline[-1]) for p in products)
         tl = np.linspace(0.0, horizon, args.exposure_points)
-        ns = NettingSet(name="mixed_state_dependent_book_cva", products=products, counterparty_id=CP, margin_period_of_risk=10 / 252)
-        cva = CVAMetric(counterparty_id=CP, recovery_rate=0.4)
+        if args.book == "cva":
+            credit = CIRPPModel(0.0, CP, HAZARDS, kappa=0.10, theta=0.01, volatility=0.02, y0=0.0001, deterministic=False)
+            model = ModelConfig([market, credit], inter_asset_correlation_matrix=[np.full((4, 1), 0.2)])
+            ns = NettingSet(name="mixed_state_dependent_book_cva", products=products, counterparty_id=CP, margin_period_of_risk=10 / 252)
+            mets, rm_kw, scheme = [CVAMetric(counterparty_id=CP, recovery_rate=0.4)], dict(exposure_timeline=tl), SimulationScheme.EULER
+        else:
+            model = market
+            ns = NettingSet(name="mixed_state_dependent_book", products=products)
+            mets = [EPEMetric(), PFEMetric(0.95)] if args.book == "ee" else [PVMetric()]
+            rm_kw, scheme = (dict(exposure_timeline=tl) if args.book == "ee" else {}), SimulationScheme.ANALYTICAL
         t0 = time.perf_counter()
-        sc = SimulationController([ns], model, RiskMetrics([cva], exposure_timeline=tl), args.paths, args.paths, 1,
-                                  SimulationScheme.EULER, backend=be)
+        sc = SimulationController([ns], model, RiskMetrics(mets, **rm_kw), args.paths, args.paths, 1, scheme, backend=be)
         t1 = time.perf_counter()
         if args.profile and rep == args.repeat - 1:
             import cProfile, pstats
@@ -120,11 +136,18 @@ def main():
             res = sc.run_simulation()
         be.synchronize()
         t2 = time.perf_counter()
-        out = dict(products=len(products), counts=counts, paths=args.paths, exposure_points=args.exposure_points,
+        out = dict(book=args.book, products=len(products), counts=counts, paths=args.paths, exposure_points=args.exposure_points,
                    timeline_size=int(sc.simulation_timeline.numel()), construct_s=t1 - t0, run_s=t2 - t1,
                    products_per_second=len(products) / (t2 - t1), timings=sc.timings, prepare=getattr(sc, 'prepare_timings', None),
-                   cva=float(res.get_results(ns.get_name(), cva.get_name(), evaluation_idx=0)),
-                   mc_error=float(res.get_mc_error(ns.get_name(), cva.get_name(), evaluation_idx=0)))
+                   lsm_singular_retries=getattr(sc, 'lsm_singular_retries', 0))
+        name = ns.get_name()
+        if args.book == "ee":
+            epe, pfe = np.asarray(res.get_results(name, mets[0].get_name())), np.asarray(res.get_results(name, mets[1].get_name()))
+            out.update(peak_epe=float(epe.max()), peak_pfe=float(pfe.max()), final_epe=float(epe[-1]), final_pfe=float(pfe[-1]))
+        else:
+            key = "cva" if args.book == "cva" else "pv"
+            out[key] = float(res.get_results(name, mets[0].get_name(), evaluation_idx=0))
+            out["mc_error"] = float(res.get_mc_error(name, mets[0].get_name(), evaluation_idx=0))
         print(json.dumps(out, default=float), flush=True)
 
 
