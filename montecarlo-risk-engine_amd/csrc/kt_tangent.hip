@@ -198,19 +198,29 @@ __global__ __launch_bounds__(MCX_BLOCK) void kt_heston(const KTArgs a)
             const Dual<PV> E = ldk_struct(&qc->E);
             const Dual<PV> m = theta + (v - theta) * E;
             const Dual<PV> s2 = v * ldk_struct(&qc->A1) + ldk_struct(&qc->A2);
-            const Dual<PV> psi = s2 / (m * m + eps);
-            const Dual<PV> invpsi = 1.0 / (psi + eps);
+            // (the seven reciprocals in three groups from one v_rcp_f64 each, the two roots of b2 as one: as in the primal step,
+            //  mcx_device.h; every denominator keeps the reference's eps)
+            const double omu = fmax(1.0 - u, eps);
+            const Dual<PV> d1 = m * m + eps, d5 = m + eps;
+            const double d15 = d1.v * d5.v;
+            const double ra = mcx_rcp(d15 * omu);
+            const double r_omu = ra * d15, ra6 = ra * omu;
+            const Dual<PV> psi = ddiv_r(s2, d1, ra6 * d5.v);
+            const Dual<PV> d2 = psi + eps, d4 = psi + 1.0;
+            const double rb = mcx_rcp(d2.v * d4.v);
+            const Dual<PV> invpsi = drcp_r(d2, rb * d4.v);
             const Dual<PV> t = dclamp_min(invpsi * 2.0 - 1.0, 0.0);
-            const Dual<PV> b2 = dclamp_min(invpsi * 2.0 - 1.0 + dsqrt(invpsi * 2.0) * dsqrt(t), 0.0);
+            const Dual<PV> b2 = dclamp_min(invpsi * 2.0 - 1.0 + dsqrt(invpsi * 2.0 * t), 0.0);
             const Dual<PV> b = dsqrt(b2);
-            const Dual<PV> aa = m / (1.0 + b2);
+            const Dual<PV> pp = dclamp(ddiv_r(psi - 1.0, d4, rb * d2.v), 0.0, 1.0 - 1e-6);
+            const Dual<PV> beta = ddiv_r(1.0 - pp, d5, ra6 * d1.v);
+            const Dual<PV> d3 = 1.0 + b2, d7 = beta + eps;
+            const double rc = mcx_rcp(d3.v * d7.v);
+            const Dual<PV> aa = ddiv_r(m, d3, rc * d7.v);
             const Dual<PV> bz = b + z1;
             const Dual<PV> v1 = aa * bz * bz;
-            const Dual<PV> pp = dclamp((psi - 1.0) / (psi + 1.0), 0.0, 1.0 - 1e-6);
-            const Dual<PV> beta = (1.0 - pp) / (m + eps);
-            const double omu = fmax(1.0 - u, eps);
             const Dual<PV> omp = dclamp_min(1.0 - pp, eps);
-            const Dual<PV> v_tail = dlog(omp * (1.0 / omu)) / (beta + eps);
+            const Dual<PV> v_tail = ddiv_r(dlog(omp * r_omu), d7, rc * d3.v);
             const Dual<PV> w_mass = ddegree(u - pp, fuzzy, 0.3);
             const Dual<PV> v2 = w_mass * v_tail;
             const Dual<PV> w = ddegree(psi - 1.5, fuzzy, 0.5);

@@ -28,7 +28,10 @@ template <int P> __device__ __forceinline__ Dual<P> dexp(const Dual<P>& a) { Dua
 template <int P> __device__ __forceinline__ Dual<P> dlog(const Dual<P>& a) { Dual<P> r; r.v = mcx_log(a.v); const double ia = mcx_rcp(a.v); for (int j = 0; j < P; ++j) r.d[j] = a.d[j] * ia; return r; }
 // sqrt: a zero tangent stays zero even where 1/(2 sqrt(x)) is infinite (x clamped to 0).  Reverse mode gets the same result
 // because torch.clamp's backward is a `where(mask, grad, 0)` that discards the inf/NaN produced by sqrt's backward.
-template <int P> __device__ __forceinline__ Dual<P> dsqrt(const Dual<P>& a) { Dual<P> r; r.v = mcx_sqrt(a.v); const double h = 0.5 / r.v; for (int j = 0; j < P; ++j) r.d[j] = a.d[j] == 0.0 ? 0.0 : a.d[j] * h; return r; }
+template <int P> __device__ __forceinline__ Dual<P> dsqrt(const Dual<P>& a) { Dual<P> r; double h; r.v = mcx_sqrt_h(a.v, h); for (int j = 0; j < P; ++j) r.d[j] = a.d[j] == 0.0 ? 0.0 : a.d[j] * h; return r; }
+// a / b with ib = 1 / b.v already known (reciprocals of several denominators from one v_rcp_f64 of their product)
+template <int P> __device__ __forceinline__ Dual<P> ddiv_r(const Dual<P>& a, const Dual<P>& b, double ib) { Dual<P> r; r.v = a.v * ib; for (int j = 0; j < P; ++j) r.d[j] = (a.d[j] - r.v * b.d[j]) * ib; return r; }
+template <int P> __device__ __forceinline__ Dual<P> drcp_r(const Dual<P>& b, double ib) { Dual<P> r; r.v = ib; const double m = -ib * ib; for (int j = 0; j < P; ++j) r.d[j] = b.d[j] * m; return r; }
 // torch.clamp(x, min=lo): gradient mask x >= lo
 template <int P> __device__ __forceinline__ Dual<P> dclamp_min(const Dual<P>& a, double lo) { Dual<P> r; const bool pass = a.v >= lo; r.v = pass ? a.v : lo; for (int j = 0; j < P; ++j) r.d[j] = pass ? a.d[j] : 0.0; return r; }
 template <int P> __device__ __forceinline__ Dual<P> dclamp(const Dual<P>& a, double lo, double hi) { Dual<P> r; const bool pass = a.v >= lo && a.v <= hi; r.v = fmin(fmax(a.v, lo), hi); for (int j = 0; j < P; ++j) r.d[j] = pass ? a.d[j] : 0.0; return r; }

@@ -129,6 +129,21 @@ __device__ __forceinline__ double mcx_sqrt(double a)
     return a > 0.0 ? g : 0.0;
 }
 
+// sqrt(a) together with h = 1 / (2 sqrt(a)) — the second Goldschmidt iterate, accurate to ~2^-50: what the derivative of a root needs
+// (mcx_dual.h dsqrt paid an IEEE division 0.5 / sqrt(a) for it).  a <= 0: (0, +inf) like 0.5 / 0.
+__device__ __forceinline__ double mcx_sqrt_h(double a, double& h_out)
+{
+    const double y = __builtin_amdgcn_rsq(a);
+    double g = a * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    const double d = fma(-g, g, a);
+    g = fma(d, h, g);
+    h_out = a > 0.0 ? h : __builtin_huge_val();
+    return a > 0.0 ? g : 0.0;
+}
+
 // the same without the residual correction: v_rsq_f64 seed + one coupled Goldschmidt step, error ~1.5 eps_seed^2 (1-2 ulp).  Used
 // where the result feeds a Monte-Carlo increment (Box-Muller radius, CIR diffusion): 3 VALU fewer per root on a kernel that is
 // bound by VALU issue

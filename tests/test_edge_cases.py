@@ -160,6 +160,82 @@ def test_library_rejects_indices_a_kernel_would_read_out_of_bounds(hip):
     jobs["w_offset"] = 1
     with pytest.raises(RuntimeError, match="outside d_W"):
         hip.lsm_step_batch(sc.book, jobs, 1, paths, W, npre)
+    # the one-call induction (mcx_lsm_run_batch) checks the same fields of every job of every step, and its step table
+    sj = np.zeros(1, dtype=_abi.LSM_SOLVE_JOB_DTYPE)
+    sj["coeff_off"][:] = -1
+    sj["scale"] = 1.0
+    with pytest.raises(RuntimeError, match="outside d_W"):
+        hip.lsm_run_batch(sc.book, jobs, sj, np.array([0, 1]), np.array([1]), paths, W, npre)
+    jobs["w_offset"] = 0
+    sj["coeff_off"][0, 0] = len(plan.coeffs) - 1                       # a [1][K] block that ends beyond the coefficient array
+    with pytest.raises(RuntimeError, match="coefficient offset"):
+        hip.lsm_run_batch(sc.book, jobs, sj, np.array([0, 1]), np.array([1]), paths, W, npre)
+    sj["coeff_off"][0, 0] = -1
+    with pytest.raises(RuntimeError, match="states"):                  # product 0 has one exercise state
+        hip.lsm_run_batch(sc.book, jobs, sj, np.array([0, 1]), np.array([2]), paths, torch.zeros(2 * npre, dtype=torch.float64, device=hip.device), npre)
+    jobs["roll_end"] = 10 ** 6
+    with pytest.raises(RuntimeError, match="roll window"):
+        hip.lsm_run_batch(sc.book, jobs, sj, np.array([0, 1]), np.array([1]), paths, W, npre)
+    jobs["roll_end"] = 0
+    # the valid table runs: atom 0 is the same number on every path, i.e. a singular system unless the job says so (rank-1 solution)
+    assert hip.lsm_run_batch(sc.book, jobs, sj, np.array([0, 1]), np.array([1]), paths, W, npre) == 1
+    sj["degenerate"] = 1
+    assert hip.lsm_run_batch(sc.book, jobs, sj, np.array([0, 1]), np.array([1]), paths, W, npre) == 0
+
+
+@pytest.mark.gpu
+def test_padded_leading_dimension_changes_no_number(hip):
+    """the path / exposure / cashflow matrices carry a padded row stride where the path count would make it a large power of two
+    (mcx._native.padded_ld): the same run on contiguous and on padded tensors, every plan, must agree bit for bit"""
+    import torch
+    from mcx import _native
+    n = 32768
+    assert _native.padded_ld(n) == n + 512 and _native.padded_ld(n + 1) == n + 1 and _native.padded_ld(4096) == 4096
+    outs = {}
+    for padded in (True, False):
+        for plan in ("fused", "semi", "unfused"):
+            build, n_pre, _n_main, steps, scheme, _diff = cases.CASES["irs_cva"]
+            ns, model, rm = build()
+            sc = cases.SimulationController(ns, model, rm, n, n_pre, steps, scheme, backend=hip if padded else _Unpadded(hip))
+            sc.materialize, sc.allow_fused, sc.main_plan = True, plan != "unfused", ("auto" if plan == "unfused" else plan)
+            res = sc.run_simulation()
+            st = sc.last_state
+            assert (st["paths"].stride(1) == n + 512) == padded and (st["expo"].stride(1) == n + 512) == padded
+            outs[(padded, plan)] = (np.array(res.results[0][0]), st["paths"].cpu().numpy(), st["expo"].cpu().numpy())
+    for plan in ("fused", "semi", "unfused"):
+        for a, b in zip(outs[(True, plan)], outs[(False, plan)]):
+            assert np.array_equal(a, b), plan
+
+
+class _Unpadded:
+    """the HIP backend with contiguous matrices (what every run used before the padded leading dimension)"""
+
+    def __init__(self, be):
+        self._be = be
+
+    def __getattr__(self, name):
+        return getattr(self._be, name)
+
+    def empty_padded(self, *shape):
+        return self._be.empty(*shape)
+
+    empty_paths = empty_padded
+
+    def generate_paths(self, sim, seed, path_offset, n_paths, inject_z=None, inject_u=None, out=None, init_state=None):
+        if out is None:
+            out = self._be.empty(sim.plan.n_dates, sim.plan.n_state, n_paths)
+        return self._be.generate_paths(sim, seed, path_offset, n_paths, inject_z, inject_u, out=out, init_state=init_state)
+
+    def eval_book(self, book, paths):
+        import ctypes as C
+        from mcx import _native
+        be, plan, n = self._be, book.plan, paths.shape[2]
+        cfs = be.empty(plan.n_netting_sets, n) if plan.desc.want_cfs else None
+        expo = be.empty(plan.n_netting_sets, plan.n_expo_rows, n) if plan.desc.want_expo else None
+        be._check(be.lib.mcx_eval_book(be.h, book.ptr, C.c_void_p(paths.data_ptr()), C.c_int64(n), C.c_int64(paths.stride(1)),
+                                       C.c_void_p(cfs.data_ptr() if cfs is not None else 0), C.c_void_p(expo.data_ptr() if expo is not None else 0),
+                                       C.c_int64(n), be._stream()), "mcx_eval_book")
+        return cfs, expo
 
 
 @pytest.mark.gpu

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3: tangent kernels without scratch — parity, configs 2 / 4 timings, kernel stats and SQ counters of config 4
-O=$PWD/gpurun_out/r3k; mkdir -p $O
+O=$PWD/gpurun_out/${OUT_TAG:-r3k}; mkdir -p $O
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; rc=$?; tail -4 $O/pytest.log; [ $rc -ne 0 ] && exit $rc
 timeout -k 10 300 python tools/run_configs.py 2 4 > $O/cfg.jsonl 2> $O/cfg.err; cut -c1-700 $O/cfg.jsonl
 ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $GRAFT_REPO_ROOT/tools/run_configs.py 2 4 > $O/prof.json 2> $O/prof.err ); echo "prof rc=$?"
