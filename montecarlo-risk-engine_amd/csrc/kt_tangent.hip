@@ -198,33 +198,43 @@ __global__ __launch_bounds__(MCX_BLOCK) void kt_heston(const KTArgs a)
             const Dual<PV> E = ldk_struct(&qc->E);
             const Dual<PV> m = theta + (v - theta) * E;
             const Dual<PV> s2 = v * ldk_struct(&qc->A1) + ldk_struct(&qc->A2);
+            // From here to the next variance the step is a function of TWO numbers, vn = G(m, s2) (+ the draws): it runs in dual
+            // numbers with two directions (d/dm, d/ds2) and the four parameter tangents follow by the chain rule,
+            // d vn = G_m d m + G_s2 d s2 — the ~30 operations of G carry 2 tangent components instead of 4.
             // (the seven reciprocals in three groups from one v_rcp_f64 each, the two roots of b2 as one: as in the primal step,
             //  mcx_device.h; every denominator keeps the reference's eps)
+            Dual<2> M, S2;
+            M.v = m.v; M.d[0] = 1.0; M.d[1] = 0.0;
+            S2.v = s2.v; S2.d[0] = 0.0; S2.d[1] = 1.0;
             const double omu = fmax(1.0 - u, eps);
-            const Dual<PV> d1 = m * m + eps, d5 = m + eps;
+            const Dual<2> d1 = M * M + eps, d5 = M + eps;
             const double d15 = d1.v * d5.v;
             const double ra = mcx_rcp(d15 * omu);
             const double r_omu = ra * d15, ra6 = ra * omu;
-            const Dual<PV> psi = ddiv_r(s2, d1, ra6 * d5.v);
-            const Dual<PV> d2 = psi + eps, d4 = psi + 1.0;
+            const Dual<2> psi = ddiv_r(S2, d1, ra6 * d5.v);
+            const Dual<2> d2 = psi + eps, d4 = psi + 1.0;
             const double rb = mcx_rcp(d2.v * d4.v);
-            const Dual<PV> invpsi = drcp_r(d2, rb * d4.v);
-            const Dual<PV> t = dclamp_min(invpsi * 2.0 - 1.0, 0.0);
-            const Dual<PV> b2 = dclamp_min(invpsi * 2.0 - 1.0 + dsqrt(invpsi * 2.0 * t), 0.0);
-            const Dual<PV> b = dsqrt(b2);
-            const Dual<PV> pp = dclamp(ddiv_r(psi - 1.0, d4, rb * d2.v), 0.0, 1.0 - 1e-6);
-            const Dual<PV> beta = ddiv_r(1.0 - pp, d5, ra6 * d1.v);
-            const Dual<PV> d3 = 1.0 + b2, d7 = beta + eps;
+            const Dual<2> invpsi = drcp_r(d2, rb * d4.v);
+            const Dual<2> t = dclamp_min(invpsi * 2.0 - 1.0, 0.0);
+            const Dual<2> b2 = dclamp_min(invpsi * 2.0 - 1.0 + dsqrt(invpsi * 2.0 * t), 0.0);
+            const Dual<2> b = dsqrt(b2);
+            const Dual<2> pp = dclamp(ddiv_r(psi - 1.0, d4, rb * d2.v), 0.0, 1.0 - 1e-6);
+            const Dual<2> beta = ddiv_r(1.0 - pp, d5, ra6 * d1.v);
+            const Dual<2> d3 = 1.0 + b2, d7 = beta + eps;
             const double rc = mcx_rcp(d3.v * d7.v);
-            const Dual<PV> aa = ddiv_r(m, d3, rc * d7.v);
-            const Dual<PV> bz = b + z1;
-            const Dual<PV> v1 = aa * bz * bz;
-            const Dual<PV> omp = dclamp_min(1.0 - pp, eps);
-            const Dual<PV> v_tail = ddiv_r(dlog(omp * r_omu), d7, rc * d3.v);
-            const Dual<PV> w_mass = ddegree(u - pp, fuzzy, 0.3);
-            const Dual<PV> v2 = w_mass * v_tail;
-            const Dual<PV> w = ddegree(psi - 1.5, fuzzy, 0.5);
-            const Dual<PV> vn = (1.0 - w) * v1 + w * v2;
+            const Dual<2> aa = ddiv_r(M, d3, rc * d7.v);
+            const Dual<2> bz = b + z1;
+            const Dual<2> v1 = aa * bz * bz;
+            const Dual<2> omp = dclamp_min(1.0 - pp, eps);
+            const Dual<2> v_tail = ddiv_r(dlog(omp * r_omu), d7, rc * d3.v);
+            const Dual<2> w_mass = ddegree(u - pp, fuzzy, 0.3);
+            const Dual<2> v2 = w_mass * v_tail;
+            const Dual<2> w = ddegree(psi - 1.5, fuzzy, 0.5);
+            const Dual<2> vn2 = (1.0 - w) * v1 + w * v2;
+            Dual<PV> vn;
+            vn.v = vn2.v;
+#pragma unroll
+            for (int j = 0; j < PV; ++j) vn.d[j] = fma(vn2.d[0], m.d[j], vn2.d[1] * s2.d[j]);
             const Dual<PL> vL = dext<PV, PL>(v), vnL = dext<PV, PL>(vn);
             const Dual<PL> var_int = dclamp_min(ldk_struct(&qc->K3) * vL, 0.0);               // K4 = 0
             const Dual<PL> vol = dsqrt(dclamp_min(var_int, eps));
