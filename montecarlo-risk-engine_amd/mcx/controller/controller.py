@@ -22,6 +22,7 @@ from .. import _abi, _native
 from ..common.enums import SimulationScheme
 from ..common.packages import FLOAT, device
 from ..engine.engine import MonteCarloEngine
+from ..helpers.host_threads import single_threaded_host
 from ..maths.regression import PolyomialRegression, RegressionFunction
 from ..metrics.metric import Metric, MetricType, mean_and_error
 from ..metrics.risk_metrics import PathwisePrimitive, RiskMetrics
@@ -49,6 +50,7 @@ def _key_to_double(keys: np.ndarray) -> np.ndarray:
 
 
 class SimulationController:
+    @single_threaded_host()
     def __init__(self, netting_sets: Sequence[NettingSet], model: Model, risk_metrics: RiskMetrics,
                  num_paths_mainsim: int, num_paths_presim: int, num_steps: int, simulation_scheme: SimulationScheme,
                  differentiate: bool = False, regression_function: RegressionFunction = PolyomialRegression(degree=2),
@@ -924,6 +926,7 @@ class SimulationController:
     shard_factory = Shard
 
     # ---- entry point (controller.py:663-709) ------------------------------------------------------------------------
+    @single_threaded_host()
     def prepare(self):
         """everything before the main simulation: descriptor compilation + (if needed) pre-simulation and LSM regression
         (the reference's perform_prepocessing, controller.py:257-292)"""
@@ -1121,6 +1124,7 @@ class SimulationController:
         self.last_state.update(paths=paths, cfs=cfs, expo=expo)
         return self._evaluate_all(self._shard, cfs, expo, paths)
 
+    @single_threaded_host()
     def run_simulation(self) -> SimulationResults:
         if self.differentiate:
             from ..aad import (_NoTangentForm, analytic_controller, run_analytic_with_autograd, run_with_bumps,

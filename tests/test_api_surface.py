@@ -99,3 +99,19 @@ def test_analytic_pv_first_and_second_derivatives(oracle):
     assert float(H["volatility"]["volatility"]) == pytest.approx(float(product.compute_dVegadSigma_analytically(model)), rel=1e-9)
     assert float(H["spot"]["volatility"]) == pytest.approx(float(H["volatility"]["spot"]), rel=1e-12)
     assert float(H["spot"]["volatility"]) == pytest.approx(-phi * d2 / sig, rel=1e-9)          # vanna
+
+
+def test_entry_points_plan_on_one_host_thread_and_restore_the_pool(oracle, monkeypatch):
+    """the controller's host-side planning runs with torch's intra-op pool at one thread (mcx/helpers/host_threads.py: a pool sized
+    from the core count spins a container with a CPU quota into CFS throttling) and hands the caller's setting back"""
+    import torch
+    before = torch.get_num_threads()
+    if before == 1:
+        pytest.skip("the pool is already single-threaded here")
+    seen = []
+    real = SimulationController._compile_all
+    monkeypatch.setattr(SimulationController, "_compile_all", lambda self: (seen.append(torch.get_num_threads()), real(self))[1])
+    sc, _ = cases.make_controller("bs_european", oracle, inject=False)
+    assert torch.get_num_threads() == before
+    sc.run_simulation()
+    assert seen == [1] and torch.get_num_threads() == before
