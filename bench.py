@@ -61,6 +61,9 @@ def build_controller(n_main, n_pre, backend):
     return SimulationController(ns, model, rm, n_main, n_pre, 5, SimulationScheme.EULER, backend=backend)
 
 
+HOST_THREADS = [1]          # torch's intra-op thread count before main() takes it to one (restored for the CPU baseline)
+
+
 def kernel_source_sha():
     h = hashlib.sha256()
     for f in KERNEL_SOURCES:
@@ -71,8 +74,10 @@ def kernel_source_sha():
 def cpu_baseline(target_seconds=12.0):
     """the CPU oracle (oracle/mcx_oracle.c, OpenMP over paths) on a bounded sample of the same workload; returns the baseline
     object and (sample paths, pre-simulation paths, oracle CVA) for the GPU-vs-CPU comparison on identical Philox counters"""
+    import torch
     from oracle_backend import OracleBackend
     be = OracleBackend()
+    torch.set_num_threads(HOST_THREADS[0])        # the oracle's OpenMP loops share the runtime main() set to one thread: all cores here
     threads = int(be.lib.orc_num_threads())
     n_pre = 16384
 
@@ -88,6 +93,7 @@ def cpu_baseline(target_seconds=12.0):
     n = int(min(1 << 20, max(16384, rate * target_seconds / S)))
     n = (n // 4096) * 4096
     t, S, cva = run(n)
+    torch.set_num_threads(1)
     obj = {"value": n * S / t, "unit": "path-steps/s", "cores": threads, "kind": "port",
            "sample": f"{n} paths x {S} steps of the same workload (path generation + book + CVA on the CPU oracle, OpenMP {threads} threads), {t:.2f} s"}
     return obj, (n, n_pre, cva)
@@ -139,6 +145,10 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
+    # the host side of a pass is a few small torch / numpy operations: one intra-op thread (a pool sized from the core count of the
+    # host spins a container with a CPU quota into CFS throttling: mcx/helpers/host_threads.py)
+    HOST_THREADS[0] = torch.get_num_threads()
+    torch.set_num_threads(1)
     torch.cuda.set_device(local_rank)
     grouped = "WORLD_SIZE" in os.environ                # under torch.distributed.run (also with one rank): RCCL process group
     if grouped:
