@@ -438,6 +438,34 @@ def test_large_book_product_batched_kernels_match_oracle(hip, oracle):
         assert np.allclose(a, b, rtol=1e-8, atol=1e-9 * max(np.abs(b).max(), 1e-300))
 
 
+@pytest.mark.parametrize("book", ["ee", "pv"])
+def test_large_book_exposure_and_pv_books_match_oracle(book, hip, oracle):
+    """the other two of the reference's large-book scripts at 1/40 of their size (ee_performance_large_netting_set.py: EPE + PFE on an
+    unsecured netting set, analytical scheme, Europeans through the closed-form exposure; pv_performance_large_netting_set.py:
+    Monte-Carlo PV): HIP against the oracle on the same Philox stream"""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("large_book_tool", os.path.join(os.path.dirname(__file__), "..", "tools", "large_book.py"))
+    lb = importlib.util.module_from_spec(spec); spec.loader.exec_module(lb)
+    ids = [f"asset_{k}" for k in range(4)]
+    out = {}
+    for name, be in (("hip", hip), ("oracle", oracle)):
+        corr = np.full((4, 4), 0.35); np.fill_diagonal(corr, 1.0)
+        market = lb.BlackScholesMulti(0.0, 0.03, ids, [95.0 + 7.5 * k for k in range(4)], [0.18 + 0.03 * k for k in range(4)], corr)
+        products = lb.build_mixed_book(ids, 80, 4, 4, 6, 10, 6, 4)
+        horizon = max(float(p.modeling_timeline[-1]) for p in products)
+        ns = lb.NettingSet(name="book", products=products)
+        if book == "ee":
+            rm = lb.RiskMetrics([lb.EPEMetric(), lb.PFEMetric(0.95)], exposure_timeline=np.linspace(0.0, horizon, 12))
+        else:
+            rm = lb.RiskMetrics([lb.PVMetric()])
+        sc = lb.SimulationController([ns], market, rm, 512, 512, 1, cases.A, backend=be)
+        res = sc.run_simulation()
+        out[name] = [np.array(m, dtype=np.float64) for m in res.results[0]]
+    for a, b in zip(out["hip"], out["oracle"]):
+        assert a.shape == b.shape and np.allclose(a[..., 0], b[..., 0], rtol=1e-9, atol=1e-9), (book, a, b)     # values
+        assert np.allclose(a[..., 1], b[..., 1], rtol=1e-6, atol=1e-9)                                           # Monte-Carlo errors
+
+
 def test_fused_kernel_timing_entry_points(hip):
     """mcx_fused_set_timing / mcx_fused_kernel_times: one duration per pass launched while armed, none when disarmed"""
     import bench
