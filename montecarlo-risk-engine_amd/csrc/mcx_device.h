@@ -298,8 +298,9 @@ __device__ __forceinline__ void step_slot(const SL& sl, int scheme_rt, int flags
             const double rb = mcx_rcp(d2 * d4);
             const double invpsi = rb * d4, r4 = rb * d2;                        // 1/(psi + eps), 1/(psi + 1)
             const double t = fmax(2.0 * invpsi - 1.0, 0.0);
-            const double b2 = fmax(2.0 * invpsi - 1.0 + mcx_sqrt(2.0 * invpsi * t), 0.0);
-            const double b = mcx_sqrt(b2);
+            // (roots that feed the Monte-Carlo increment: seed + one coupled Goldschmidt step, 1-2 ulp, as for the CIR diffusion)
+            const double b2 = fmax(2.0 * invpsi - 1.0 + mcx_sqrt_g(2.0 * invpsi * t), 0.0);
+            const double b = mcx_sqrt_g(b2);
             const double pp = fmin(fmax((psi - 1.0) * r4, 0.0), 1.0 - 1e-6);
             const double beta = (1.0 - pp) * r5;
             const double d3 = 1.0 + b2, d7 = beta + eps;
@@ -312,7 +313,7 @@ __device__ __forceinline__ void step_slot(const SL& sl, int scheme_rt, int flags
             const double w = degree_of_truth(psi - 1.5, fuzzy, 0.5);
             const double vn = (1.0 - w) * v1 + w * v2;
             const double var_int = fmax(aux[4] * v + aux[5] * vn, 0.0);
-            const double vol = mcx_sqrt(fmax(var_int, eps));
+            const double vol = mcx_sqrt_gp(fmax(var_int, eps));
             s0 = logS + rate * dt + aux[1] + aux[2] * v + aux[3] * vn + vol * zc0;
             s1 = vn;
         }
