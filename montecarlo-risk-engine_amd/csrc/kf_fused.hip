@@ -490,7 +490,7 @@ extern "C" int mcx_fused_create(mcx_handle* h, const mcx_sim* sim, const mcx_boo
         }
         return o;
     };
-    const std::vector<DevEvent>& hev = book->h_events;
+    const DevEventVec& hev = book->h_events;
     const std::vector<DevTerm>& hte = book->h_terms;
     auto devatom_to_mcx = [](const DevAtom& q) { mcx_atom o; o.t_idx = q.t_idx; o.col = q.col; o.a = q.a; o.d = q.d; o.b = q.b; o.c0 = q.c0; o.c1 = q.c1; return o; };
 

@@ -1,4 +1,7 @@
 // mcx_api.hip — handle, book (descriptor flattening + upload) and small shared host helpers of libmcx_hip.so.
+#include <algorithm>
+#include <thread>
+
 #include "mcx_device.h"
 
 extern "C" int mcx_abi_version(void) { return MCX_ABI_VERSION; }
@@ -131,19 +134,31 @@ extern "C" int mcx_book_create(mcx_handle* h, const mcx_book_desc* d, mcx_book**
         terms[i].den = d->terms[i].den;
         terms[i].pad = 0;
     }
-    // the flattened events are built in place in the book's host image (4 x 10^5 events of a 5,000-product book are 60 MB: a
-    // second vector and its copy were a third of this call); the vector's value-initialisation is the one zeroing pass
-    std::vector<DevEvent>& events = b->h_events;
+    // the flattened events are built in place in the book's host image (4 x 10^5 events of a 5,000-product book are 64 MB: a
+    // second vector and its copy were a third of this call), by a few threads for big books: each zeroes and fills its own chunk
+    DevEventVec& events = b->h_events;
     events.resize(d->n_events > 0 ? d->n_events : 1);
     DevAtom none; memset(&none, 0, sizeof(none)); none.col = -1;
-    for (int i = 0; i < d->n_events; ++i) {
-        const mcx_event& e = d->events[i];
-        DevEvent& o = events[i];
-        o.kind = e.kind; o.term_begin = e.term_begin; o.term_end = e.term_end; o.coeff_off = e.coeff_off; o.row = e.expo_row;
-        o.strike = e.strike; o.sign = e.sign;
-        for (int q = 0; q < 4; ++q) o.aux[q] = e.aux[q];
-        o.num = flat_atom(d->atoms[e.num_atom]);
-        o.x = e.x_atom >= 0 ? flat_atom(d->atoms[e.x_atom]) : none;
+    auto convert = [&](int i0, int i1) {
+        if (i1 > i0) memset((void*)&events[i0], 0, sizeof(DevEvent) * (size_t)(i1 - i0));
+        for (int i = i0; i < i1; ++i) {
+            const mcx_event& e = d->events[i];
+            DevEvent& o = events[i];
+            o.kind = e.kind; o.term_begin = e.term_begin; o.term_end = e.term_end; o.coeff_off = e.coeff_off; o.row = e.expo_row;
+            o.strike = e.strike; o.sign = e.sign;
+            for (int q = 0; q < 4; ++q) o.aux[q] = e.aux[q];
+            o.num = flat_atom(d->atoms[e.num_atom]);
+            o.x = e.x_atom >= 0 ? flat_atom(d->atoms[e.x_atom]) : none;
+        }
+    };
+    if (d->n_events <= 0) memset((void*)&events[0], 0, sizeof(DevEvent));
+    const int n_thr = d->n_events >= (1 << 16) ? 8 : 1;
+    if (n_thr == 1) convert(0, d->n_events);
+    else {
+        std::vector<std::thread> pool;
+        const int per = (d->n_events + n_thr - 1) / n_thr;
+        for (int t = 0; t < n_thr; ++t) pool.emplace_back(convert, std::min(t * per, d->n_events), std::min((t + 1) * per, d->n_events));
+        for (auto& th : pool) th.join();
     }
     // exposure rows: the first writer of a (netting set, row) stores, later ones accumulate; rows nobody writes need a memset
     b->ns_has_writer.assign((size_t)d->n_netting_sets * (d->n_expo_rows > 0 ? d->n_expo_rows : 1), 0);

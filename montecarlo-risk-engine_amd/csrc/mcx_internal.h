@@ -7,7 +7,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/mcx.h"
@@ -80,6 +82,19 @@ struct DevEvent {
     DevAtom x;
 };
 
+// std::vector whose resize() does not zero its elements (4 x 10^5 events of a 5,000-product book are 64 MB: the zeroing pass and
+// the page faults of the first touch belong to the threads that fill the chunks)
+template <class T>
+struct mcx_noinit_alloc : std::allocator<T> {
+    template <class U> struct rebind { using other = mcx_noinit_alloc<U>; };
+    template <class U, class... A> void construct(U* p, A&&... a)
+    {
+        if constexpr (sizeof...(A) == 0) ::new ((void*)p) U;
+        else ::new ((void*)p) U(std::forward<A>(a)...);
+    }
+};
+typedef std::vector<DevEvent, mcx_noinit_alloc<DevEvent>> DevEventVec;
+
 // value polynomial of an event (mcx_vpoly.hip): sum of the event's terms = p(t), t = fma(x, ih, ms), x = paths[t_idx][col], valid
 // for lo <= x <= hi; n_blk blocks of MCX_VPOLY_BLK coefficients at coef_off, highest power first (zero-padded in front)
 #define MCX_VPOLY_BLK 4
@@ -105,7 +120,7 @@ struct mcx_book {
     struct DevBridge* d_bridge;      // RNG state of Brownian-bridge barrier events (mcx_device.h), one device struct per book
     const double** d_bridge_inject;  // [n_products] device table of injected-uniform pointers (nullptr entries allowed)
     std::vector<mcx_atom> h_atoms;
-    std::vector<DevEvent> h_events;
+    DevEventVec h_events;          // (default-initialising allocator: mcx_book_create fills it from several threads, first touch included)
     std::vector<DevTerm> h_terms;
     std::vector<int32_t> h_event_t_idx;
     std::vector<int32_t> h_event_num_atom, h_event_x_atom, h_term_atom;
