@@ -180,36 +180,50 @@ class SimulationController:
         return out
 
     # The three per-product predicates are asked several times per product and run (compile, atom registration, regression, metric
-    # evaluation): answers are kept per product object until the next compilation (`_compile` / `invalidate` clear the memo)
-    def _memo(self, kind: str, product: Product, fn):
+    # evaluation): answers are kept per product object until the next compilation (`_compile` / `invalidate` clear the memo).  The
+    # hit path is one dictionary lookup (no closure is built): books of 10^4-10^5 products ask ~6 times per product.
+    def _can_use_analytic_exposure_for_product(self, product: Product) -> bool:
         memo = self.__dict__.setdefault("_pred_memo", {})
-        key = (kind, id(product))
+        key = ("analytic", id(product))
         hit = memo.get(key)
         if hit is None:
-            hit = memo[key] = bool(fn())
+            ok = {MetricType.PV, MetricType.EPE, MetricType.PFE}
+            hit = memo[key] = bool(all(m.metric_type in ok for m in self.risk_metrics.metrics) and product.supports_analytic_exposure(self.model))
         return hit
 
-    def _can_use_analytic_exposure_for_product(self, product: Product) -> bool:
-        ok = {MetricType.PV, MetricType.EPE, MetricType.PFE}
-        return self._memo("analytic", product, lambda: all(m.metric_type in ok for m in self.risk_metrics.metrics)
-                          and product.supports_analytic_exposure(self.model))
-
     def _product_requires_regression(self, product: Product) -> bool:
-        def ask():
-            if len(product.regression_timeline) > 0:
-                return True
-            if not self.risk_metrics.requires_exposure_profiles():
-                return False
-            return not self._can_use_analytic_exposure_for_product(product)
-        return self._memo("regression", product, ask)
+        memo = self.__dict__.setdefault("_pred_memo", {})
+        key = ("regression", id(product))
+        hit = memo.get(key)
+        if hit is None:
+            if len(self._timelines(product)[1]) > 0:
+                hit = True
+            elif not self.risk_metrics.requires_exposure_profiles():
+                hit = False
+            else:
+                hit = not self._can_use_analytic_exposure_for_product(product)
+            memo[key] = hit
+        return hit
 
     def _can_skip_monte_carlo_for_product(self, product: Product) -> bool:
-        def ask():
-            if self.risk_metrics.requires_exposure_profiles():
-                return False
-            return all(m.metric_type == MetricType.PV and m.evaluation_type == Metric.EvaluationType.ANALYTICAL
-                       and product.supports_analytic_pv(self.model) for m in self.risk_metrics.metrics)
-        return self._memo("skip", product, ask)
+        memo = self.__dict__.setdefault("_pred_memo", {})
+        key = ("skip", id(product))
+        hit = memo.get(key)
+        if hit is None:
+            hit = memo[key] = bool((not self.risk_metrics.requires_exposure_profiles()) and all(
+                m.metric_type == MetricType.PV and m.evaluation_type == Metric.EvaluationType.ANALYTICAL
+                and product.supports_analytic_pv(self.model) for m in self.risk_metrics.metrics))
+        return hit
+
+    @staticmethod
+    def _timelines(product: Product):
+        """(payment dates, regression dates) of a product as tuples of floats, converted once per timeline tensor (a tensor ->
+        list conversion per question was 5 conversions per product and run)"""
+        hit = product.__dict__.get("_tl_tuples")
+        pt, rt = product.product_timeline, product.regression_timeline
+        if hit is None or hit[0] is not pt or hit[1] is not rt or hit[2] != (pt._version, rt._version):
+            hit = product.__dict__["_tl_tuples"] = (pt, rt, (pt._version, rt._version), tuple(pt.tolist()), tuple(rt.tolist()))
+        return hit[3], hit[4]
 
     def _get_requests(self):
         reqs = defaultdict(set)
@@ -248,7 +262,7 @@ class SimulationController:
             self._expo_coeff_base.append(off)
             off += E * S * K
             self._reg_coeff_base.append(off)
-            off += len(p.regression_timeline) * S * K
+            off += len(self._timelines(p)[1]) * S * K
             self._extra_coeff_base.append(off)
             off += p._n_extra_coeffs()
         expo_atom_cache: dict = {}
@@ -307,6 +321,7 @@ class SimulationController:
         # ---- phase A: per product — cash events (atoms / terms are created in the order the reference visits them) ----------------
         n_prod = len(self.products)
         cash_rows: list = []
+        cash_templates: dict = {}
         cash_start = np.zeros(n_prod + 1, dtype=np.int64)
         ev_len = np.zeros(n_prod, dtype=np.int64)
         n_states = np.zeros(n_prod, dtype=np.int32)
@@ -319,9 +334,18 @@ class SimulationController:
             n_states[p_i], init_state[p_i] = S, p.get_initial_state()
             skip = self._can_skip_monte_carlo_for_product(p)
             comp.current_product = p_i
-            cash = [] if skip else p._cash_events(comp)
-            pdates = tuple(p.product_timeline.tolist())
-            assert skip or len(cash) == len(pdates)
+            pdates = self._timelines(p)[0]
+            # products that differ from an earlier one in strike and sign only (Product._cash_template_key) re-use its event rows —
+            # the same atoms and the SAME term range — with their own two numbers
+            tkey = None if skip or not hasattr(p, "_cash_template_key") else p._cash_template_key()
+            tmpl = cash_templates.get(tkey) if tkey is not None else None
+            if tmpl is not None:
+                cash_rows.extend(p._cash_template_fill(r) for r in tmpl)
+                cash = []
+            else:
+                cash = [] if skip else p._cash_events(comp)
+                assert skip or len(cash) == len(pdates)
+            first_row = len(cash_rows)
             for ce in cash:
                 nt = ce.time if ce.num_time is None else ce.num_time
                 num = num_atom_cache.get(nt)
@@ -336,6 +360,8 @@ class SimulationController:
                         comp.coeff_init[co + k_] = float(v_)
                 tr = comp.add_terms(ce.terms)
                 cash_rows.append((ce.kind, comp.tidx(ce.time), num, x, tr[0], tr[1], co, -1, float(ce.strike), float(ce.sign), tuple(ce.aux)))
+            if tkey is not None and tmpl is None and all(ce.reg_idx is None and not ce.coeff_params for ce in cash):
+                cash_templates[tkey] = cash_rows[first_row:]
             cash_start[p_i + 1] = len(cash_rows)
             if skip:
                 continue
@@ -407,8 +433,7 @@ class SimulationController:
     def _regression_schedule(self, p_i: int, product: Product):
         """backward list of (t_reg, roll_begin, roll_end, store_prod_idx|None, store_expo_idx|None).  Memoised on the
         product's timelines: books of thousands of products share a handful of distinct schedules."""
-        pdates = tuple(product.product_timeline.tolist())
-        preg = tuple(product.regression_timeline.tolist())
+        pdates, preg = self._timelines(product)
         cache = self.__dict__.setdefault("_sched_cache", {})
         hit = cache.get((pdates, preg))
         if hit is not None:
@@ -563,14 +588,16 @@ class SimulationController:
         (reference: controller.py:289-383, one Python iteration per product and date)."""
         be = self.backend
         S_of = [p.get_num_states() for _, p, _, _ in jobs]
-        w_off, tot = [], 0
-        for S in S_of:
-            w_off.append(tot)
-            tot += S * n_local
+        S_arr = np.asarray(S_of, dtype=np.int64)
+        w_off = np.concatenate([[0], np.cumsum(S_arr * n_local)])
+        tot = int(w_off[-1])
         W = be.zeros(max(tot, 1))
         mirror = np.zeros(len(self.book_plan.coeffs))                 # host image of the coefficients this pass produces
         # products sharing (schedule, explanatory asset, state count) differ only in their ids and offsets: one vectorised
         # block of the job table per class and step instead of a Python iteration per (product, date)
+        pi_all = np.fromiter((job[0] for job in jobs), dtype=np.int64, count=len(jobs))
+        reg_all = np.asarray(self._reg_coeff_base, dtype=np.int64)[pi_all]
+        expo_all = np.asarray(self._expo_coeff_base, dtype=np.int64)[pi_all]
         classes: dict = {}
         for j, (p_i, p, sched, atoms) in enumerate(jobs):
             classes.setdefault((id(sched), id(atoms), S_of[j]), []).append(j)
@@ -580,11 +607,9 @@ class SimulationController:
             L = len(sched)
             lo = np.array([x_range[x][0] for _, x in atoms]); hi = np.array([x_range[x][1] for _, x in atoms])
             deg = ~(hi > lo)
-            cls.append(dict(S=S, L=L, members=np.array(members),
-                            p_i=np.array([jobs[m][0] for m in members], dtype=np.int32),
-                            w_off=np.array([w_off[m] for m in members], dtype=np.int64),
-                            reg_base=np.array([self._reg_coeff_base[jobs[m][0]] for m in members], dtype=np.int64),
-                            expo_base=np.array([self._expo_coeff_base[jobs[m][0]] for m in members], dtype=np.int64),
+            m_ = np.asarray(members)
+            cls.append(dict(S=S, L=L, members=m_, p_i=pi_all[m_].astype(np.int32), w_off=w_off[m_],
+                            reg_base=reg_all[m_], expo_base=expo_all[m_],
                             r0=[s[1] for s in sched], r1=[s[2] for s in sched],
                             prod_idx=[-1 if s[3] is None else s[3] for s in sched],
                             expo_idx=[-1 if s[4] is None else s[4] for s in sched],
@@ -679,7 +704,7 @@ class SimulationController:
             S = S_of[j]
             b0 = self._expo_coeff_base[p_i]
             self.regression_coeffs[p_i] = mt[b0:b0 + E * S * K].view(E, S, K)
-            R = len(p.regression_timeline)
+            R = len(self._timelines(p)[1])
             if R:
                 b1 = self._reg_coeff_base[p_i]
                 p.regression_coeffs = mt[b1:b1 + R * S * K].view(R, S, K)

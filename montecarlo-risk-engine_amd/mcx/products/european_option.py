@@ -40,6 +40,17 @@ class EuropeanOption(Product):
         und = self.underlying_requests[0].underlying_asset
         return [CashEvent(_abi.EV_OPTION, self._T, und._value_terms(ctx, self._T), strike=self._K, sign=self._sign())]
 
+    def _cash_template_key(self):
+        """options on the spot of one asset with one maturity differ in strike and sign only: the controller builds their cash event
+        (atoms, terms) once per key and re-uses it (books of 10^4-10^5 Europeans: pv_performance_large_netting_set.py).  None: no
+        shortcut (any other underlying carries its own parameters)."""
+        from .equity import Equity
+        und = self.underlying_requests[0].underlying_asset
+        return ("european", self._T, und.get_asset_id()) if type(und) is Equity else None
+
+    def _cash_template_fill(self, row: tuple) -> tuple:
+        return row[:8] + (float(self._K), float(self._sign())) + row[10:]
+
     # ---- Black-Scholes closed forms (european_option.py:88-145) ------------------------------------------------
     def _bs_price(self, spot: float, rate: float, sigma: float, tau: float) -> float:
         d1 = (math.log(spot / self._K) + (rate + 0.5 * sigma ** 2) * tau) / (sigma * math.sqrt(tau))
