@@ -216,7 +216,9 @@ __global__ __launch_bounds__(MCX_BLOCK) void kt_heston(const KTArgs a)
             const double rb = mcx_rcp(d2.v * d4.v);
             const Dual<2> invpsi = drcp_r(d2, rb * d4.v);
             const Dual<2> t = dclamp_min(invpsi * 2.0 - 1.0, 0.0);
-            const Dual<2> b2 = dclamp_min(invpsi * 2.0 - 1.0 + dsqrt(invpsi * 2.0 * t), 0.0);
+            Dual<2> root = dsqrt(invpsi * 2.0 * t);
+            if (invpsi.v < 0.0) root.v = __builtin_nan("");          // torch.sqrt(2 / psi) of a negative psi (mcx_device.h, QE step)
+            const Dual<2> b2 = dclamp_min(invpsi * 2.0 - 1.0 + root, 0.0);
             const Dual<2> b = dsqrt(b2);
             const Dual<2> pp = dclamp(ddiv_r(psi - 1.0, d4, rb * d2.v), 0.0, 1.0 - 1e-6);
             const Dual<2> beta = ddiv_r(1.0 - pp, d5, ra6 * d1.v);

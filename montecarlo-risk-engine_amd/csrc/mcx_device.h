@@ -299,7 +299,13 @@ __device__ __forceinline__ void step_slot(const SL& sl, int scheme_rt, int flags
             const double invpsi = rb * d4, r4 = rb * d2;                        // 1/(psi + eps), 1/(psi + 1)
             const double t = fmax(2.0 * invpsi - 1.0, 0.0);
             // (roots that feed the Monte-Carlo increment: seed + one coupled Goldschmidt step, 1-2 ulp, as for the CIR diffusion)
-            const double b2 = fmax(2.0 * invpsi - 1.0 + mcx_sqrt_g(2.0 * invpsi * t), 0.0);
+            // The smoothed scheme can take the variance — and with it s2 and psi — below zero; the reference then
+            // takes torch.sqrt of the negative 2/psi (heston.py:203) and the path is NaN from there on (torch.clamp keeps a NaN).
+            // Reproduced: the merged root below is 0 there (t = 0), so the NaN is put in by hand, and b2's clamp keeps it.
+            double root = mcx_sqrt_g(2.0 * invpsi * t);
+            root = invpsi < 0.0 ? __builtin_nan("") : root;
+            const double b2u = 2.0 * invpsi - 1.0 + root;
+            const double b2 = b2u < 0.0 ? 0.0 : b2u;
             const double b = mcx_sqrt_g(b2);
             const double pp = fmin(fmax((psi - 1.0) * r4, 0.0), 1.0 - 1e-6);
             const double beta = (1.0 - pp) * r5;

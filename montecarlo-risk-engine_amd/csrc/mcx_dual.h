@@ -33,7 +33,7 @@ template <int P> __device__ __forceinline__ Dual<P> dsqrt(const Dual<P>& a) { Du
 template <int P> __device__ __forceinline__ Dual<P> ddiv_r(const Dual<P>& a, const Dual<P>& b, double ib) { Dual<P> r; r.v = a.v * ib; for (int j = 0; j < P; ++j) r.d[j] = (a.d[j] - r.v * b.d[j]) * ib; return r; }
 template <int P> __device__ __forceinline__ Dual<P> drcp_r(const Dual<P>& b, double ib) { Dual<P> r; r.v = ib; const double m = -ib * ib; for (int j = 0; j < P; ++j) r.d[j] = b.d[j] * m; return r; }
 // torch.clamp(x, min=lo): gradient mask x >= lo
-template <int P> __device__ __forceinline__ Dual<P> dclamp_min(const Dual<P>& a, double lo) { Dual<P> r; const bool pass = a.v >= lo; r.v = pass ? a.v : lo; for (int j = 0; j < P; ++j) r.d[j] = pass ? a.d[j] : 0.0; return r; }
+template <int P> __device__ __forceinline__ Dual<P> dclamp_min(const Dual<P>& a, double lo) { Dual<P> r; const bool pass = a.v >= lo; r.v = a.v < lo ? lo : a.v;   /* (a NaN value stays NaN: torch.clamp) */ for (int j = 0; j < P; ++j) r.d[j] = pass ? a.d[j] : 0.0; return r; }
 template <int P> __device__ __forceinline__ Dual<P> dclamp(const Dual<P>& a, double lo, double hi) { Dual<P> r; const bool pass = a.v >= lo && a.v <= hi; r.v = fmin(fmax(a.v, lo), hi); for (int j = 0; j < P; ++j) r.d[j] = pass ? a.d[j] : 0.0; return r; }
 template <int P> __device__ __forceinline__ Dual<P> ddegree(const Dual<P>& x, bool fuzzy, double eps)
 {

@@ -140,8 +140,8 @@ __device__ __forceinline__ double mcx_sqrt_h(double a, double& h_out)
     h = fma(h, r, h);
     const double d = fma(-g, g, a);
     g = fma(d, h, g);
-    h_out = a > 0.0 ? h : __builtin_huge_val();
-    return a > 0.0 ? g : 0.0;
+    h_out = a <= 0.0 ? __builtin_huge_val() : h;               // (a NaN argument stays NaN in both, like sqrt)
+    return a <= 0.0 ? 0.0 : g;
 }
 
 // the same without the residual correction: v_rsq_f64 seed + one coupled Goldschmidt step, error ~1.5 eps_seed^2 (1-2 ulp).  Used
@@ -154,7 +154,7 @@ __device__ __forceinline__ double mcx_sqrt_g(double a)
     const double h = 0.5 * y;
     const double r = fma(-h, g, 0.5);
     g = fma(g, r, g);
-    return a > 0.0 ? g : 0.0;
+    return a <= 0.0 ? 0.0 : g;                                 // (a NaN argument stays NaN, like sqrt)
 }
 
 // the same for a > 0 (the squared Box-Muller radius -2 log u, u < 1): no zero test

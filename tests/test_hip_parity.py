@@ -100,6 +100,44 @@ def test_philox_paths_through_the_qe_scheme(hip, oracle):
     assert np.allclose(out["hip"], out["oracle"], rtol=1e-11, atol=1e-13)
 
 
+@pytest.mark.parametrize("smoothing", [False, True], ids=["hard", "fuzzy"])
+def test_heston_qe_random_parameters_gpu_vs_oracle(smoothing, hip, oracle):
+    """the QE step with its reciprocals taken in groups from one v_rcp_f64 of a product (mcx_device.h) against the oracle's IEEE
+    divisions, over 24 random parameter sets that reach both branches, tiny and large variances, strong vol-of-vol and long steps:
+    the products of denominators must neither overflow nor lose the reference's eps floors.  Hard branch: a 1-ulp difference of
+    psi or u may flip a branch for a vanishing share of the paths; fuzzy branch: the smoothed scheme's variance goes negative
+     and a path may come arbitrarily close to the pole of 1/(psi + eps) — the same allowance."""
+    from mcx.common.enums import SimulationScheme
+    from mcx.engine.engine import MonteCarloEngine
+    from mcx.models.heston import HestonModel
+    rng = np.random.default_rng(20261005)
+    n, worst = 8192, 0.0
+    for case in range(24):
+        v0 = float(10.0 ** rng.uniform(-6.0, -0.5))
+        theta = float(10.0 ** rng.uniform(-6.0, -0.5))
+        kappa = float(10.0 ** rng.uniform(-2.0, 1.2))
+        sigma = float(10.0 ** rng.uniform(-2.0, 0.5))
+        rho = float(rng.uniform(-0.95, 0.95))
+        rate = float(rng.uniform(-0.02, 0.08))
+        horizon = float(10.0 ** rng.uniform(-1.0, 1.0))
+        model = HestonModel(0.0, 100.0, rate, sigma, rho, kappa, theta, v0)
+        model.perform_smoothing = smoothing
+        tl = np.linspace(horizon / 4, horizon, 4)
+        out = {}
+        steps = int(rng.integers(1, 6))
+        for be in (hip, oracle):
+            eng = MonteCarloEngine(tl, SimulationScheme.QE, model, n, steps, backend=be, path_offset=1000003 * case)
+            out[be.name] = eng.generate_paths_native().cpu().numpy()
+        # without smoothing every state is finite; with it the reference takes the root of a negative 2 / psi for many of these
+        # parameter sets and the path is NaN from there on (13 of the 24 sets on the oracle): the same entries must be NaN here
+        if not smoothing:
+            assert np.all(np.isfinite(out["hip"])) and np.all(np.isfinite(out["oracle"])), (case, v0, theta, kappa, sigma)
+        bad = ~np.isclose(out["hip"], out["oracle"], rtol=1e-9, atol=1e-12, equal_nan=True)
+        worst = max(worst, float(bad.mean()))
+        assert bad.mean() <= 2e-3, (case, smoothing, bad.mean(), dict(v0=v0, theta=theta, kappa=kappa, sigma=sigma, rho=rho, horizon=horizon, steps=steps))
+    assert worst <= 2e-3
+
+
 def _oracle_pairs(oracle, words):
     import ctypes as C
     n = words.shape[1]
