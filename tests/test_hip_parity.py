@@ -138,6 +138,64 @@ def test_heston_qe_random_parameters_gpu_vs_oracle(smoothing, hip, oracle):
     assert worst <= 2e-3
 
 
+def test_random_model_parameters_gpu_vs_oracle(hip, oracle):
+    """paths of every model family and scheme on random parameter sets — strong / vanishing mean reversion, volatilities over three
+    decades, correlations up to +-0.95, CIR++ starts a hair above zero, a four-asset BlackScholesMulti with a random correlation
+    matrix inside a ModelConfig with credit — against the oracle on identical Philox counters.  None of these steps contains a hard
+    indicator: the paths must agree entry by entry."""
+    from mcx.common.enums import SimulationScheme as SS
+    from mcx.engine.engine import MonteCarloEngine
+    from mcx.models.black_scholes import BlackScholesModel
+    from mcx.models.black_scholes_multi import BlackScholesMulti
+    from mcx.models.cirpp import CIRPPModel
+    from mcx.models.model_config import ModelConfig
+    from mcx.models.vasicek import VasicekModel
+    rng = np.random.default_rng(7)
+    n = 4096
+
+    def lu(lo, hi):
+        return float(10.0 ** rng.uniform(np.log10(lo), np.log10(hi)))
+
+    def cir():
+        kappa, theta = lu(0.02, 3.0), lu(1e-3, 0.2)
+        vol = float(rng.uniform(0.05, 0.95)) * np.sqrt(2 * kappa * theta)              # inside the Feller condition the constructor asserts
+        return CIRPPModel(0.0, "cp", cases.HAZARDS, kappa=kappa, theta=theta, volatility=vol, y0=lu(1e-9, 0.05))
+
+    def vas(asset_id=None):
+        return VasicekModel(0.0, float(rng.uniform(-0.01, 0.08)), float(rng.uniform(-0.01, 0.1)), lu(1e-3, 5.0), lu(1e-4, 0.1), asset_id=asset_id)
+
+    def multi():
+        a = rng.normal(size=(4, 4))
+        c = a @ a.T
+        d = np.sqrt(np.diag(c))
+        ids = [f"a{k}" for k in range(4)]
+        corr = 0.5 * np.eye(4) + 0.5 * c / np.outer(d, d)                                # (well inside the positive-definite cone: a credit column is added)
+        return BlackScholesMulti(0.0, float(rng.uniform(0.0, 0.06)), ids, [lu(10.0, 500.0) for _ in ids], [lu(0.02, 0.9) for _ in ids], corr)
+
+    builders = [
+        ("bs", lambda: BlackScholesModel(0, lu(1.0, 1e3), float(rng.uniform(-0.02, 0.1)), lu(0.01, 1.5)), (SS.ANALYTICAL, SS.EULER)),
+        ("vasicek", lambda: vas(), (SS.ANALYTICAL, SS.EULER)),
+        ("cirpp", cir, (SS.EULER,)),
+        ("vasicek+cirpp", lambda: ModelConfig([vas("ir"), cir()], inter_asset_correlation_matrix=np.array([float(rng.uniform(-0.95, 0.95))])), (SS.EULER,)),
+        ("multi", multi, (SS.ANALYTICAL, SS.EULER)),
+        ("multi+cirpp", lambda: ModelConfig([multi(), cir()], inter_asset_correlation_matrix=[rng.uniform(-0.15, 0.15, size=(4, 1))]), (SS.EULER,)),
+    ]
+    for name, build, schemes in builders:
+        for rep in range(6):
+            model = build()
+            horizon = lu(0.05, 20.0)
+            tl = np.linspace(0.0, horizon, 6) if rep % 2 else np.linspace(horizon / 5, horizon, 5)
+            steps = int(rng.integers(1, 5))
+            for scheme in schemes:
+                out = {}
+                for be in (hip, oracle):
+                    eng = MonteCarloEngine(tl, scheme, model, n, steps, backend=be, path_offset=977 * rep)
+                    out[be.name] = eng.generate_paths_native().cpu().numpy()
+                assert np.all(np.isfinite(out["oracle"])), (name, rep, scheme)
+                bad = ~np.isclose(out["hip"], out["oracle"], rtol=1e-10, atol=1e-13)
+                assert not bad.any(), (name, rep, scheme.name, float(bad.mean()), float(np.abs(out["hip"] - out["oracle"]).max()))
+
+
 def _oracle_pairs(oracle, words):
     import ctypes as C
     n = words.shape[1]
