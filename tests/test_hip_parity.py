@@ -196,6 +196,64 @@ def test_random_model_parameters_gpu_vs_oracle(hip, oracle):
                 assert not bad.any(), (name, rep, scheme.name, float(bad.mean()), float(np.abs(out["hip"] - out["oracle"]).max()))
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "unfused"])
+def test_random_rate_books_gpu_vs_oracle(fused, hip, oracle):
+    """the compiled date programs of the one-launch kernel and the event interpreter on RANDOM linear books: 1-4 swaps / bonds / floaters
+    with random schedules on Vasicek + CIR++ credit, netting sets with random threshold and margin period of risk, exposure dates that
+    do and do not coincide with payment dates, CVA + PV + EPE + ENE + PFE — every metric value against the oracle on identical counters"""
+    from mcx.products.bond import Bond
+    from mcx.products.swap import InterestRateSwap, IRSType
+    rng = np.random.default_rng(11)
+    for case in range(10):
+        def build():
+            r = np.random.default_rng(1000 + case)                       # the same book for both backends
+            ir = cases.VasicekModel(0.0, float(r.uniform(0.0, 0.06)), float(r.uniform(0.0, 0.08)), float(10 ** r.uniform(-2, 0.5)),
+                                    float(10 ** r.uniform(-3, -1.3)), asset_id="ir")
+            kappa, theta = float(10 ** r.uniform(-1.5, 0.3)), float(10 ** r.uniform(-2.5, -1))
+            cr = cases.CIRPPModel(0.0, "cp", cases.HAZARDS, kappa=kappa, theta=theta, volatility=float(r.uniform(0.1, 0.9) * np.sqrt(2 * kappa * theta)),
+                                  y0=float(10 ** r.uniform(-5, -2)), deterministic=bool(r.integers(0, 4) == 0))
+            model = cases.ModelConfig([ir, cr], inter_asset_correlation_matrix=np.array([float(r.uniform(-0.9, 0.9))]))
+            sets, horizon = [], 0.0
+            for k in range(int(r.integers(1, 3))):
+                prods = []
+                for q in range(int(r.integers(1, 4))):
+                    mat = float(r.choice([1.0, 1.5, 2.0, 3.0, 5.0]))
+                    horizon = max(horizon, mat)
+                    kind = int(r.integers(0, 3))
+                    if kind == 0:
+                        p = InterestRateSwap(0.0, mat, float(10 ** r.uniform(-1, 1.5)), float(r.uniform(0.0, 0.07)), float(r.choice([0.25, 0.5, 1.0])),
+                                             float(r.choice([0.25, 0.5])), IRSType.PAYER if r.integers(0, 2) else IRSType.RECEIVER, "ir")
+                    elif kind == 1:
+                        p = Bond(0.0, mat, float(10 ** r.uniform(-1, 1)), float(r.choice([0.25, 0.5, 1.0])), True, float(r.uniform(0.0, 0.06)), "ir")
+                    else:
+                        p = Bond(0.0, mat, float(10 ** r.uniform(-1, 1)), float(r.choice([0.25, 0.5])), True, None, "ir")          # floater
+                    p.name = f"p{k}_{q}"
+                    prods.append(p)
+                kw = {}
+                if r.integers(0, 2):
+                    kw["threshold"] = float(10 ** r.uniform(-3, -1))
+                if r.integers(0, 2):
+                    kw["margin_period_of_risk"] = float(r.choice([0.25, 0.5]))
+                sets.append(cases.NettingSet(name=f"ns{k}", products=prods, counterparty_id="cp", **kw))
+            tl = np.arange(0.0, horizon + 1e-9, 0.25) if r.integers(0, 2) else np.linspace(0.0, horizon, int(r.integers(5, 12)))
+            mets = [cases.CVAMetric("cp", float(r.uniform(0.2, 0.6))), cases.PVMetric(), cases.EPEMetric(), cases.ENEMetric(), cases.PFEMetric(0.9)]
+            return sets, model, cases.RiskMetrics(mets, exposure_timeline=tl)
+        res = {}
+        for be in (hip, oracle):
+            ns, model, rm = build()
+            sc = cases.SimulationController(ns, model, rm, 4096, 2048, int(rng.integers(1, 4)) if be is hip else steps, cases.E, backend=be)
+            if be is hip:
+                steps = sc.num_steps
+                sc.allow_fused = fused
+            res[be.name] = sc.run_simulation().results
+        for ns_i in range(len(res["hip"])):
+            for m_i in range(len(res["hip"][ns_i])):
+                a, b = np.array(res["hip"][ns_i][m_i], dtype=np.float64), np.array(res["oracle"][ns_i][m_i], dtype=np.float64)
+                assert np.allclose(a[:, 0], b[:, 0], rtol=1e-8, atol=1e-10), (case, ns_i, m_i, a[:, 0], b[:, 0])
+                if m_i != 4:                                                    # (PFE carries no Monte-Carlo error)
+                    assert np.allclose(a[:, 1], b[:, 1], rtol=1e-5, atol=1e-11), (case, ns_i, m_i, a[:, 1], b[:, 1])
+
+
 def _oracle_pairs(oracle, words):
     import ctypes as C
     n = words.shape[1]
