@@ -196,48 +196,52 @@ def test_random_model_parameters_gpu_vs_oracle(hip, oracle):
                 assert not bad.any(), (name, rep, scheme.name, float(bad.mean()), float(np.abs(out["hip"] - out["oracle"]).max()))
 
 
+def _random_rate_book(case, metrics=None):
+    """1-2 netting sets of 1-3 swaps / bonds / floaters with random schedules on Vasicek + CIR++ credit (the same book for a given case)"""
+    from mcx.products.bond import Bond
+    from mcx.products.swap import InterestRateSwap, IRSType
+    r = np.random.default_rng(1000 + case)                       # the same book for both backends
+    ir = cases.VasicekModel(0.0, float(r.uniform(0.0, 0.06)), float(r.uniform(0.0, 0.08)), float(10 ** r.uniform(-2, 0.5)),
+                            float(10 ** r.uniform(-3, -1.3)), asset_id="ir")
+    kappa, theta = float(10 ** r.uniform(-1.5, 0.3)), float(10 ** r.uniform(-2.5, -1))
+    cr = cases.CIRPPModel(0.0, "cp", cases.HAZARDS, kappa=kappa, theta=theta, volatility=float(r.uniform(0.1, 0.9) * np.sqrt(2 * kappa * theta)),
+                          y0=float(10 ** r.uniform(-5, -2)), deterministic=bool(r.integers(0, 4) == 0))
+    model = cases.ModelConfig([ir, cr], inter_asset_correlation_matrix=np.array([float(r.uniform(-0.9, 0.9))]))
+    sets, horizon = [], 0.0
+    for k in range(int(r.integers(1, 3))):
+        prods = []
+        for q in range(int(r.integers(1, 4))):
+            mat = float(r.choice([1.0, 1.5, 2.0, 3.0, 5.0]))
+            horizon = max(horizon, mat)
+            kind = int(r.integers(0, 3))
+            if kind == 0:
+                p = InterestRateSwap(0.0, mat, float(10 ** r.uniform(-1, 1.5)), float(r.uniform(0.0, 0.07)), float(r.choice([0.25, 0.5, 1.0])),
+                                     float(r.choice([0.25, 0.5])), IRSType.PAYER if r.integers(0, 2) else IRSType.RECEIVER, "ir")
+            elif kind == 1:
+                p = Bond(0.0, mat, float(10 ** r.uniform(-1, 1)), float(r.choice([0.25, 0.5, 1.0])), True, float(r.uniform(0.0, 0.06)), "ir")
+            else:
+                p = Bond(0.0, mat, float(10 ** r.uniform(-1, 1)), float(r.choice([0.25, 0.5])), True, None, "ir")          # floater
+            p.name = f"p{k}_{q}"
+            prods.append(p)
+        kw = {}
+        if r.integers(0, 2):
+            kw["threshold"] = float(10 ** r.uniform(-3, -1))
+        if r.integers(0, 2):
+            kw["margin_period_of_risk"] = float(r.choice([0.25, 0.5]))
+        sets.append(cases.NettingSet(name=f"ns{k}", products=prods, counterparty_id="cp", **kw))
+    tl = np.arange(0.0, horizon + 1e-9, 0.25) if r.integers(0, 2) else np.linspace(0.0, horizon, int(r.integers(5, 12)))
+    mets = [cases.CVAMetric("cp", float(r.uniform(0.2, 0.6))), cases.PVMetric(), cases.EPEMetric(), cases.ENEMetric(), cases.PFEMetric(0.9)]
+    return sets, model, cases.RiskMetrics(mets if metrics is None else metrics(), exposure_timeline=tl)
+
+
 @pytest.mark.parametrize("fused", [True, False], ids=["fused", "unfused"])
 def test_random_rate_books_gpu_vs_oracle(fused, hip, oracle):
     """the compiled date programs of the one-launch kernel and the event interpreter on RANDOM linear books: 1-4 swaps / bonds / floaters
     with random schedules on Vasicek + CIR++ credit, netting sets with random threshold and margin period of risk, exposure dates that
     do and do not coincide with payment dates, CVA + PV + EPE + ENE + PFE — every metric value against the oracle on identical counters"""
-    from mcx.products.bond import Bond
-    from mcx.products.swap import InterestRateSwap, IRSType
     rng = np.random.default_rng(11)
     for case in range(10):
-        def build():
-            r = np.random.default_rng(1000 + case)                       # the same book for both backends
-            ir = cases.VasicekModel(0.0, float(r.uniform(0.0, 0.06)), float(r.uniform(0.0, 0.08)), float(10 ** r.uniform(-2, 0.5)),
-                                    float(10 ** r.uniform(-3, -1.3)), asset_id="ir")
-            kappa, theta = float(10 ** r.uniform(-1.5, 0.3)), float(10 ** r.uniform(-2.5, -1))
-            cr = cases.CIRPPModel(0.0, "cp", cases.HAZARDS, kappa=kappa, theta=theta, volatility=float(r.uniform(0.1, 0.9) * np.sqrt(2 * kappa * theta)),
-                                  y0=float(10 ** r.uniform(-5, -2)), deterministic=bool(r.integers(0, 4) == 0))
-            model = cases.ModelConfig([ir, cr], inter_asset_correlation_matrix=np.array([float(r.uniform(-0.9, 0.9))]))
-            sets, horizon = [], 0.0
-            for k in range(int(r.integers(1, 3))):
-                prods = []
-                for q in range(int(r.integers(1, 4))):
-                    mat = float(r.choice([1.0, 1.5, 2.0, 3.0, 5.0]))
-                    horizon = max(horizon, mat)
-                    kind = int(r.integers(0, 3))
-                    if kind == 0:
-                        p = InterestRateSwap(0.0, mat, float(10 ** r.uniform(-1, 1.5)), float(r.uniform(0.0, 0.07)), float(r.choice([0.25, 0.5, 1.0])),
-                                             float(r.choice([0.25, 0.5])), IRSType.PAYER if r.integers(0, 2) else IRSType.RECEIVER, "ir")
-                    elif kind == 1:
-                        p = Bond(0.0, mat, float(10 ** r.uniform(-1, 1)), float(r.choice([0.25, 0.5, 1.0])), True, float(r.uniform(0.0, 0.06)), "ir")
-                    else:
-                        p = Bond(0.0, mat, float(10 ** r.uniform(-1, 1)), float(r.choice([0.25, 0.5])), True, None, "ir")          # floater
-                    p.name = f"p{k}_{q}"
-                    prods.append(p)
-                kw = {}
-                if r.integers(0, 2):
-                    kw["threshold"] = float(10 ** r.uniform(-3, -1))
-                if r.integers(0, 2):
-                    kw["margin_period_of_risk"] = float(r.choice([0.25, 0.5]))
-                sets.append(cases.NettingSet(name=f"ns{k}", products=prods, counterparty_id="cp", **kw))
-            tl = np.arange(0.0, horizon + 1e-9, 0.25) if r.integers(0, 2) else np.linspace(0.0, horizon, int(r.integers(5, 12)))
-            mets = [cases.CVAMetric("cp", float(r.uniform(0.2, 0.6))), cases.PVMetric(), cases.EPEMetric(), cases.ENEMetric(), cases.PFEMetric(0.9)]
-            return sets, model, cases.RiskMetrics(mets, exposure_timeline=tl)
+        build = lambda: _random_rate_book(case)
         res = {}
         for be in (hip, oracle):
             ns, model, rm = build()
@@ -734,6 +738,43 @@ def test_forward_mode_cva_against_reference_autograd_and_bumps(hip):
         scale = np.abs(out[False][k]).max()
         assert np.allclose(out[True][k], out[False][k], rtol=2e-5, atol=2e-6 * scale), (k, out[True][k], out[False][k])
     assert np.allclose(out[True][2], out[False][2], rtol=1e-12)
+
+
+@pytest.mark.parametrize("case", [0, 3, 5, 8])
+def test_forward_mode_on_random_rate_books_against_bumps(case, hip):
+    """the dual-number pass (csrc/kt_book.hip: paths, regressions, book, CVA / EPE / ENE / PV in dual numbers) on random linear books
+    against central differences on the same Philox counters: every sensitivity of every metric date"""
+    import mcx.aad as aad
+    from mcx.helpers.host_threads import single_threaded_host
+    mets = lambda: [cases.CVAMetric("cp", 0.4), cases.PVMetric(), cases.EPEMetric(), cases.ENEMetric()]
+    # Two step sizes: thresholds and margin periods put kinks into the exposures, and a central difference over a kink is off by
+    # O(h) (case 5: d CVA / d sigma_r is 7.22328124e-3 in dual numbers and at h = 1e-6 theta, 7.22246e-3 at 1e-5 theta), while the
+    # small parameters of the credit model lose digits to cancellation at the small step.  Every component must agree with one of them.
+    grads = {}
+    for tag, h in (("tangent", None), ("fd_small", 1e-6), ("fd_default", 1e-5)):
+        ns, model, rm = _random_rate_book(case, mets)
+        sc = cases.SimulationController(ns, model, rm, 8192, 4096, 2, cases.E, differentiate=True, backend=hip)
+        if h is None:
+            r = sc.run_simulation()
+            assert sc.timings.get("tangent") is True, sc.timings
+        else:
+            saved = aad.bump_size
+            aad.bump_size = lambda theta, h=h: h * max(abs(theta), 1e-2)
+            try:
+                with single_threaded_host():
+                    r = aad.run_with_bumps(sc)
+            finally:
+                aad.bump_size = saved
+        grads[tag] = r.derivatives
+    for ns_i in range(len(grads["tangent"])):
+        for m_i in range(len(grads["tangent"][ns_i])):
+            a = np.array(grads["tangent"][ns_i][m_i], dtype=np.float64)
+            fds = [np.array(grads[t][ns_i][m_i], dtype=np.float64) for t in ("fd_small", "fd_default")]
+            scale = max(np.abs(f).max() for f in fds) + 1e-300
+            ok = np.zeros(a.shape, dtype=bool)
+            for f in fds:
+                ok |= np.isclose(a, f, rtol=2e-5, atol=2e-6 * scale)
+            assert ok.all(), (case, ns_i, m_i, a[~ok], [f[~ok] for f in fds])
 
 
 def test_table_box_muller_normals_moments_and_tails(hip):
