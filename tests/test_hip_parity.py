@@ -592,6 +592,59 @@ def test_exercise_products_take_the_forward_mode_path(hip):
             assert np.all(np.abs(a - b) <= 2e-6 * scale + 1e-9), (ns_i, m_i, a, b)
 
 
+@pytest.mark.parametrize("case", [0, 1, 2, 3])
+def test_forward_mode_through_random_exercise_products_against_replayed_bumps(case, hip):
+    """random Bermudan swaptions (Vasicek) and American options (Black-Scholes): every EPE / ENE / PV sensitivity of the ONE forward-mode
+    pass (frozen exercise policy, tangents through the taken branch) against central differences of bumped runs that REPLAY the base
+    run's decisions — the derivative the reference's tape defines (bermudan_option.py:122-128)"""
+    import mcx.aad as aad
+    from mcx.helpers.host_threads import single_threaded_host
+    from mcx.products.swap import InterestRateSwap, IRSType
+
+    def build():
+        r = np.random.default_rng(300 + case)
+        if case % 2 == 0:
+            model = cases.VasicekModel(0.0, float(r.uniform(0.01, 0.05)), float(r.uniform(0.01, 0.07)), float(10 ** r.uniform(-1.5, 0)), float(10 ** r.uniform(-2.5, -1.6)))
+            mat = float(r.choice([2.0, 3.0, 4.0]))
+            und = InterestRateSwap(0.0, mat, 1.0, float(r.uniform(0.02, 0.05)), 0.25, 0.25, IRSType.PAYER if r.integers(0, 2) else IRSType.RECEIVER)
+            n_ex = int(r.integers(4, 12))
+            prod = cases.BermudanOption(und, [float(t) for t in np.linspace(mat / (n_ex + 1), mat * n_ex / (n_ex + 1), n_ex)], 0.0, cases.OptionType.CALL)
+            tl = np.linspace(0.0, mat, 9)
+        else:
+            model = cases.BlackScholesModel(0.0, float(r.uniform(80, 120)), float(r.uniform(0.0, 0.06)), float(r.uniform(0.15, 0.6)))
+            mat = float(r.choice([1.0, 2.0, 3.0]))
+            prod = cases.AmericanOption(cases.Equity("id"), mat, int(r.integers(4, 13)), float(r.uniform(85, 115)),
+                                        cases.OptionType.PUT if r.integers(0, 2) else cases.OptionType.CALL)
+            tl = np.linspace(0.0, mat, 7)
+        mets = [cases.EPEMetric(), cases.ENEMetric(), cases.PVMetric()]
+        return [cases.NettingSet(name="ex", products=[prod])], model, cases.RiskMetrics(mets, exposure_timeline=tl)
+
+    grads = {}
+    for tag, h in (("tangent", None), ("fd_small", 1e-6), ("fd_default", 1e-5)):
+        ns, model, rm = build()
+        sc = cases.SimulationController(ns, model, rm, 8192, 8192, 2, cases.E, differentiate=True, backend=hip)
+        if h is None:
+            r = sc.run_simulation()
+            assert sc.timings.get("tangent") is True and sc.timings.get("forward_mode_passes") == 1, sc.timings
+        else:
+            saved = aad.bump_size
+            aad.bump_size = lambda theta, h=h: h * max(abs(theta), 1e-2)
+            try:
+                with single_threaded_host():
+                    r = aad.run_with_bumps(sc)
+            finally:
+                aad.bump_size = saved
+        grads[tag] = r.derivatives
+    for m_i in range(3):
+        a = np.array(grads["tangent"][0][m_i], dtype=np.float64)
+        fds = [np.array(grads[t][0][m_i], dtype=np.float64) for t in ("fd_small", "fd_default")]
+        scale = max(np.abs(f).max() for f in fds) + 1e-300
+        ok = np.zeros(a.shape, dtype=bool)
+        for f in fds:
+            ok |= np.isclose(a, f, rtol=2e-5, atol=2e-6 * scale)
+        assert ok.all(), (case, m_i, a[~ok], [f[~ok] for f in fds])
+
+
 def test_basket_anchors_of_the_reference_tests(hip):
     """tests/pytests/test_model_config.py:18-71 and test_pv_basket_option.py:16-69 at their own sizes: arithmetic basket 12.60,
     geometric basket = its closed form 10.9551100513373 (ModelConfig of 4 BS models, 1 M paths; BlackScholesMulti with the
