@@ -97,6 +97,31 @@ def test_four_emulated_ranks_match_the_single_shard_run(name, n_main, n_pre, hip
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", [1, 4, 7])
+def test_random_rate_books_on_three_emulated_ranks(case, hip):
+    """random linear books (test_hip_parity._random_rate_book: thresholds, margin periods, CVA + PV + EPE + ENE + PFE) with the paths
+    on three ranks of uneven size: every metric of every netting set as on one shard"""
+    from mcx import _native
+    from test_hip_parity import _random_rate_book
+    n_main, n_pre = 30011, 9001
+
+    def build(be):
+        ns, model, rm = _random_rate_book(case)
+        sc = cases.SimulationController(ns, model, rm, n_main, n_pre, 2, cases.E, backend=be)
+        sc.materialize = False
+        return sc
+
+    ref = _results(build(hip).run_simulation())
+    out, calls = run_ranks(3, lambda rank: build(_native.HipBackend(0)), lambda sc, rank: _results(sc.run_simulation()))
+    assert calls["all_reduce"] + calls["all_gather"] > 0
+    for rank, got in enumerate(out):
+        for ns_r, ns_g in zip(ref, got):
+            for m_i, (m_r, m_g) in enumerate(zip(ns_r, ns_g)):
+                assert np.allclose(m_r[:, 0], m_g[:, 0], rtol=1e-9, atol=1e-12), (case, rank, m_i, m_r[:, 0], m_g[:, 0])
+                assert np.allclose(m_r[:, 1], m_g[:, 1], rtol=1e-6, atol=1e-11, equal_nan=True), (case, rank, m_i)
+
+
+@pytest.mark.gpu
 def test_pipelined_passes_gather_the_records_of_every_emulated_rank(hip):
     """bench.py's loop (fused_pass_begin / fused_pass_end: record gather on a side stream while the next kernel runs) on 3
     emulated ranks: every pass must deliver the CVA of ALL paths"""
