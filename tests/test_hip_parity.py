@@ -645,6 +645,48 @@ def test_forward_mode_through_random_exercise_products_against_replayed_bumps(ca
         assert ok.all(), (case, m_i, a[~ok], [f[~ok] for f in fds])
 
 
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_european_tangent_kernel_on_random_books_against_bumps(case, hip):
+    """kt_bs (csrc/kt_tangent.hip: Black-Scholes paths in dual numbers, several options in several netting sets) on random spot / rate /
+    volatility, strikes and maturities, analytical and Euler scheme: PV sensitivities against central differences on the same counters"""
+    import mcx.aad as aad
+    from mcx.helpers.host_threads import single_threaded_host
+
+    def build():
+        r = np.random.default_rng(40 + case)
+        model = cases.BlackScholesModel(0.0, float(r.uniform(50, 200)), float(r.uniform(-0.01, 0.08)), float(r.uniform(0.1, 0.7)))
+        sets = []
+        for k in range(int(r.integers(1, 4))):
+            prods = []
+            for q in range(int(r.integers(1, 4))):
+                o = cases.EuropeanOption(cases.Equity(), float(r.choice([0.5, 1.0, 2.0, 3.0])), float(model.get_model_params()[0]) * float(r.uniform(0.7, 1.3)),
+                                         cases.OptionType.CALL if r.integers(0, 2) else cases.OptionType.PUT)
+                o.name = f"o{k}_{q}"
+                prods.append(o)
+            sets.append(cases.NettingSet(name=f"ns{k}", products=prods))
+        return sets, model, cases.RiskMetrics([cases.PVMetric()]), (cases.A if case % 2 == 0 else cases.E)
+
+    grads = {}
+    for tag, h in (("tangent", None), ("fd", 1e-6)):
+        ns, model, rm, scheme = build()
+        sc = cases.SimulationController(ns, model, rm, 1 << 17, 0, 7, scheme, differentiate=True, backend=hip)
+        if h is None:
+            r = sc.run_simulation()
+            assert sc.timings.get("tangent") is True, sc.timings
+        else:
+            saved = aad.bump_size
+            aad.bump_size = lambda theta, h=h: h * max(abs(theta), 1e-2)
+            try:
+                with single_threaded_host():
+                    r = aad.run_with_bumps(sc)
+            finally:
+                aad.bump_size = saved
+        grads[tag] = r.derivatives
+    for ns_i in range(len(grads["tangent"])):
+        a, b = np.array(grads["tangent"][ns_i][0], dtype=np.float64), np.array(grads["fd"][ns_i][0], dtype=np.float64)
+        assert np.allclose(a, b, rtol=2e-5, atol=2e-6 * np.abs(b).max()), (case, ns_i, a, b)
+
+
 def test_basket_anchors_of_the_reference_tests(hip):
     """tests/pytests/test_model_config.py:18-71 and test_pv_basket_option.py:16-69 at their own sizes: arithmetic basket 12.60,
     geometric basket = its closed form 10.9551100513373 (ModelConfig of 4 BS models, 1 M paths; BlackScholesMulti with the
