@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import logging
 import math
+import threading
 import time
 from collections import defaultdict
 from typing import Sequence
@@ -478,9 +479,6 @@ class SimulationController:
             eng.inject_z, eng.inject_u = self._inject["pre"]
         paths = eng.generate_paths_native()
         self.last_state["paths_pre"] = paths
-        self._collapse_values(shard, paths)
-        self._set_bridge_rng(eng.seed, off, "bridge_pre")
-        self._set_exercise_replay("pre", n_local)
         K = self.regression_function.get_degree()
         comp = self._comp
         jobs = []
@@ -489,6 +487,10 @@ class SimulationController:
                 continue
             sched = self._regression_schedule(p_i, p)
             jobs.append((p_i, p, sched, self._regression_atoms(sched, p.asset_ids[0])))
+        self._book_ready()               # (everything above ran beside a big book's upload)
+        self._collapse_values(shard, paths)
+        self._set_bridge_rng(eng.seed, off, "bridge_pre")
+        self._set_exercise_replay("pre", n_local)
         if len(self._comp.atoms) != len(self.book_plan.atoms):
             raise RuntimeError("internal: regression atoms must be registered before the book is frozen")
         # range of every explanatory variable (conditioning of the monomial basis; exact-degeneracy detection)
@@ -965,6 +967,7 @@ class SimulationController:
         self._sim = be.sim_create(self.sim_plan)
         if self.requires_regression:
             self._perform_regression(self._shard, self.sim_plan, self._sim)
+        self._book_ready()
         self.prepare_timings = dict(compile=t1 - t0, presim_and_regression=time.perf_counter() - t1)
         off, n_local = self._shard.split(self.num_paths_mainsim)
         self._main_engine = MonteCarloEngine(self.simulation_timeline, self.simulation_scheme, self.model, n_local,
@@ -1225,9 +1228,36 @@ class SimulationController:
         if self.requires_regression:
             self._register_regression_atoms()
         self.book_plan = BookPlan(self._comp, *self._plan_args)
-        self.book = self.backend.book_create(self.book_plan)
+        if len(self.book_plan.events) >= (1 << 16):
+            # a big book's flattening + upload (mcx_book_create: ~35 ms for 4 x 10^5 events, in C, the GIL released) runs beside the
+            # host work that does not need the book yet — the sub-step plan, the pre-simulation launch, the regression job lists;
+            # _book_ready() joins before the first call that takes the book
+            box: dict = {}
+
+            def work(plan=self.book_plan, be=self.backend):
+                try:
+                    box["book"] = be.book_create(plan)
+                except BaseException as e:                                # noqa: BLE001 — re-raised by _book_ready
+                    box["err"] = e
+            th = threading.Thread(target=work, name="mcx-book-create")
+            th.start()
+            self.book, self._book_pending = None, (th, box)
+        else:
+            self.book = self.backend.book_create(self.book_plan)
         self._coeffs_at_upload = self.book_plan.coeffs.copy()
         self._compiled_key = key
+
+    def _book_ready(self):
+        """the uploaded book (waits for a mcx_book_create still running beside the planning, see _compile_all)"""
+        pend = self.__dict__.pop("_book_pending", None)
+        if pend is not None:
+            th, box = pend
+            th.join()
+            if "err" in box:
+                self._compiled_key = None
+                raise box["err"]
+            self.book = box["book"]
+        return self.book
 
     def _evaluate_all(self, shard, cfs, expo, paths, fused_records=None):
         analytical = [[0.0 for _ in self.risk_metrics.metrics] for _ in self.netting_sets]
