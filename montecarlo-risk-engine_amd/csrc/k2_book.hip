@@ -425,22 +425,15 @@ extern "C" int mcx_eval_book(mcx_handle* h, const mcx_book* b, const double* d_p
         if (n_chunks < 2) n_chunks = 1;
     }
     if (n_chunks == 1) {
-        bool barrier = false;
-        for (const DevEvent& e : b->h_events) barrier = barrier || (e.kind == MCX_EV_OPTION && (e.aux[0] == 4.0 || e.aux[0] == 5.0));
+        const bool barrier = b->has_barrier;
 #ifndef MCX_K2_PPL
 #define MCX_K2_PPL 2
 #endif
         constexpr int PPL = MCX_K2_PPL;
         if (!barrier && grid >= 8 * h->n_cu) {          // enough paths to fill the chip at PPL paths per lane
             const int gv = (int)((n_paths + (int64_t)MCX_BLOCK * PPL - 1) / ((int64_t)MCX_BLOCK * PPL));
-            int feat = 0;
-            for (const DevEvent& e : b->h_events) {
-                if (e.kind == MCX_EV_OPTION && e.aux[0] != 0.0) feat |= K2F_EXOTIC;
-                if (e.kind == MCX_EV_EXERCISE) feat |= K2F_EXERCISE;
-                if (e.kind == MCX_EV_EXPO_BS) feat |= K2F_BS_EXPO;
-            }
-            for (const DevProduct& pr : b->h_products) if (pr.n_states != 1) feat |= K2F_EXERCISE;
-            for (const DevTerm& tm : b->h_terms) if (tm.den >= 0) feat |= K2F_DEN;
+            const int feat = (b->has_exotic ? K2F_EXOTIC : 0) | (b->has_exercise ? K2F_EXERCISE : 0) | (b->has_bs_expo ? K2F_BS_EXPO : 0) |
+                             (b->has_den ? K2F_DEN : 0);          // (found once, at mcx_book_create)
 #ifndef MCX_K2_PPL_LIGHT
 #define MCX_K2_PPL_LIGHT 4
 #endif

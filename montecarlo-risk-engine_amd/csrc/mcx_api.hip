@@ -191,6 +191,16 @@ extern "C" int mcx_book_create(mcx_handle* h, const mcx_book_desc* d, mcx_book**
     b->h_event_num_atom.resize(d->n_events); b->h_event_x_atom.resize(d->n_events); b->h_term_atom.resize(d->n_terms);
     for (int i = 0; i < d->n_events; ++i) { b->h_event_num_atom[i] = d->events[i].num_atom; b->h_event_x_atom[i] = d->events[i].x_atom; }
     for (int i = 0; i < d->n_terms; ++i) b->h_term_atom[i] = d->terms[i].atom;
+    b->has_barrier = b->has_exotic = b->has_exercise = b->has_bs_expo = b->has_den = false;
+    for (int i = 0; i < d->n_events; ++i) {
+        const mcx_event& e = d->events[i];
+        if (e.kind == MCX_EV_OPTION && (e.aux[0] == 4.0 || e.aux[0] == 5.0)) b->has_barrier = true;
+        if (e.kind == MCX_EV_OPTION && e.aux[0] != 0.0) b->has_exotic = true;
+        if (e.kind == MCX_EV_EXERCISE) b->has_exercise = true;
+        if (e.kind == MCX_EV_EXPO_BS) b->has_bs_expo = true;
+    }
+    for (int p = 0; p < d->n_products; ++p) if (d->products[p].n_states != 1) b->has_exercise = true;
+    for (int i = 0; i < d->n_terms; ++i) if (d->terms[i].den >= 0) b->has_den = true;
     b->expo_needs_memset = false;
     if (d->want_expo)
         for (size_t q = 0; q < (size_t)d->n_netting_sets * d->n_expo_rows; ++q)

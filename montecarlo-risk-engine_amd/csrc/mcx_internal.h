@@ -138,6 +138,9 @@ struct mcx_book {
     std::vector<double> vpoly_key;        // (tolerance, candidate events and ranges) of the last mcx_book_collapse_values
     std::vector<uint8_t> ns_has_writer;   // [n_netting_sets * n_expo_rows]
     bool expo_needs_memset;
+    // event families the book contains, found once at mcx_book_create (mcx_eval_book picks its kernel specialisation from them: a
+    // scan of the host events per call walked 64 MB for a 5,000-product book)
+    bool has_barrier, has_exotic, has_exercise, has_bs_expo, has_den;
 };
 
 // derived per-step constants of the Euler maps, written by mcx_sim_create into otherwise unused entries of the DEVICE copy of
