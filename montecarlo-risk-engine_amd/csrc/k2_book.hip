@@ -131,6 +131,9 @@ __global__ __launch_bounds__(MCX_BLOCK) void k2_eval_book(const K2Args a)
         for (int q = pr.ev_begin; q < pr.ev_end; ++q) {
             const DevEvent e = ldk_struct(&a.events[q]);
             if (e.kind <= MCX_EV_EXERCISE) {
+                // a cashflow / payoff of a product without exercise states feeds the cashflow output alone: nothing to do when no
+                // metric asks for discounted cashflows (a CVA / exposure run: the payments of a swap were 150 of its 151 exponentials)
+                if (!a.want_cfs && pr.n_states == 1 && e.kind != MCX_EV_EXERCISE) continue;
                 acc += dev_cash_event(e, a.terms, a.atoms, a.coeffs, K, a.paths, D, ld, i, s, a.bridge, a.ex_mode,
                                       a.ex_mode ? a.ex_bits + (int64_t)q * a.ex_ld + i : nullptr, a.vpoly, a.vcoef);
             } else {
@@ -230,6 +233,9 @@ __global__ __launch_bounds__(MCX_BLOCK) void k2_eval_book_v(const K2Args a)
                 }
             }
             if (e.kind <= MCX_EV_EXERCISE) {
+                // (as in the one-path kernel: a stateless product's cash event is dead without a cashflow output; its numeraire
+                //  stays evaluated above — the exposure event of the same date re-uses it, flags bit 1)
+                if (!a.want_cfs && pr.n_states == 1 && e.kind != MCX_EV_EXERCISE) continue;
                 double common[PPL], own[PPL], glog[PPL];
 #pragma unroll
                 for (int q = 0; q < PPL; ++q) { common[q] = 0.0; own[q] = 0.0; glog[q] = 0.0; }
