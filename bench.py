@@ -379,6 +379,10 @@ def main():
             cb, (n_s, n_pre_s, cva_cpu) = cpu_baseline()
             out["cpu_baseline"] = cb
             out["gpu_over_cpu"] = value / cb["value"]
+            # the reference's own PyTorch-CPU path cannot be timed here (/root/reference does not exist on the GPU box): the survey's
+            # figure for this configuration at 1/10 of the paths, measured in the build container, for orientation only
+            out["reference_cpu_survey"] = {"value": 1.27e7, "unit": "path-steps/s (main path generation alone; 4.0e6 end to end)", "cores": 8,
+                                           "where": "BASELINE.md section 2: 100k + 100k paths, 8 vCPU Xeon 2.1 GHz, build container"}
             # PV/CVA vs the CPU reference path: the same sample on the GPU, identical Philox counters
             sc_s = build_controller(n_s, n_pre_s, be)
             sc_s.prepare()
