@@ -263,7 +263,7 @@ class SimulationController:
             self._expo_coeff_base.append(off)
             off += E * S * K
             self._reg_coeff_base.append(off)
-            off += len(self._timelines(p)[1]) * S * K
+            off += int(p.regression_timeline.shape[0]) * S * K          # (.shape: no tensor -> list conversion for 10^5 products)
             self._extra_coeff_base.append(off)
             off += p._n_extra_coeffs()
         expo_atom_cache: dict = {}
@@ -330,22 +330,42 @@ class SimulationController:
         cash_classes: dict = {}              # layout -> products
         expo_classes: dict = {}              # (asset, analytic, n_states, layout) -> products
         bs_in: dict = {}                     # analytic exposure inputs of a product
+        memo = self.__dict__.setdefault("_pred_memo", {})
+        self._member_rec = {}                # product index -> template record (products that took the shortcut below)
+        mc_products, mc_set = self._mc_products, self._mc_set
         for p_i, p in enumerate(self.products):
+            # Products that differ from an earlier one in strike and sign only (Product._cash_template_key: Europeans on one asset
+            # and maturity — 39,400 of the 49,900 products of the reference's PV book) take everything else from that product's
+            # record: event rows (the same atoms and the SAME term range), state count, layout, classes, predicates.
+            tk = getattr(p, "_cash_template_key", None)
+            tkey = tk() if tk is not None else None
+            rec = cash_templates.get(tkey) if tkey is not None else None
+            if rec is not None and rec["complete"]:
+                n_states[p_i], init_state[p_i] = rec["S"], rec["init"]
+                for r in rec["rows"]:
+                    cash_rows.append(p._cash_template_fill(r))
+                cash_start[p_i + 1] = len(cash_rows)
+                ev_len[p_i] = rec["ev_len"]
+                rec["cash_members"].append(p_i)
+                if rec["expo_members"] is not None:
+                    rec["expo_members"].append(p_i)
+                    if rec["analytic"]:
+                        bs_in[p_i] = (float(p._K), float(p._sign())) + rec["bs"]
+                mc_products.append(p_i)
+                mc_set.add(p_i)
+                pid = id(p)
+                memo[("skip", pid)], memo[("analytic", pid)], memo[("regression", pid)] = False, rec["analytic"], rec["requires_reg"]
+                self._member_rec[p_i] = rec
+                continue
             S = p.get_num_states()
             n_states[p_i], init_state[p_i] = S, p.get_initial_state()
             skip = self._can_skip_monte_carlo_for_product(p)
             comp.current_product = p_i
             pdates = self._timelines(p)[0]
-            # products that differ from an earlier one in strike and sign only (Product._cash_template_key) re-use its event rows —
-            # the same atoms and the SAME term range — with their own two numbers
-            tkey = None if skip or not hasattr(p, "_cash_template_key") else p._cash_template_key()
-            tmpl = cash_templates.get(tkey) if tkey is not None else None
-            if tmpl is not None:
-                cash_rows.extend(p._cash_template_fill(r) for r in tmpl)
-                cash = []
-            else:
-                cash = [] if skip else p._cash_events(comp)
-                assert skip or len(cash) == len(pdates)
+            if skip:
+                tkey = None
+            cash = [] if skip else p._cash_events(comp)
+            assert skip or len(cash) == len(pdates)
             first_row = len(cash_rows)
             for ce in cash:
                 nt = ce.time if ce.num_time is None else ce.num_time
@@ -361,24 +381,32 @@ class SimulationController:
                         comp.coeff_init[co + k_] = float(v_)
                 tr = comp.add_terms(ce.terms)
                 cash_rows.append((ce.kind, comp.tidx(ce.time), num, x, tr[0], tr[1], co, -1, float(ce.strike), float(ce.sign), tuple(ce.aux)))
-            if tkey is not None and tmpl is None and all(ce.reg_idx is None and not ce.coeff_params for ce in cash):
-                cash_templates[tkey] = cash_rows[first_row:]
+            rec = None
+            if tkey is not None and all(ce.reg_idx is None and not ce.coeff_params for ce in cash):
+                rec = cash_templates[tkey] = dict(rows=cash_rows[first_row:], complete=False)
             cash_start[p_i + 1] = len(cash_rows)
             if skip:
                 continue
             lay = layout_of(pdates)
             ev_len[p_i] = lay[2]
-            cash_classes.setdefault(id(lay), (lay, []))[1].append(p_i)
+            cash_members = cash_classes.setdefault(id(lay), (lay, []))[1]
+            cash_members.append(p_i)
+            expo_members, analytic = None, False
             if want_expo:
                 analytic = self._can_use_analytic_exposure_for_product(p)
                 asset = p.asset_ids[0]
                 expo_template(asset)                                                  # (creates the asset's exposure atoms HERE, as before)
-                expo_classes.setdefault((asset, analytic, S, id(lay)), (lay, []))[1].append(p_i)
+                expo_members = expo_classes.setdefault((asset, analytic, S, id(lay)), (lay, []))[1]
+                expo_members.append(p_i)
                 if analytic:
                     _s, sig_p, rate_p = p._bs_inputs(self.model)
                     bs_in[p_i] = (float(p._K), float(p._sign()), float(sig_p), float(rate_p), float(p.exercise_date[0]))
-            self._mc_products.append(p_i)
-            self._mc_set.add(p_i)
+            mc_products.append(p_i)
+            mc_set.add(p_i)
+            if rec is not None:
+                rec.update(complete=True, S=S, init=int(init_state[p_i]), ev_len=lay[2], cash_members=cash_members, expo_members=expo_members,
+                           analytic=analytic, bs=bs_in[p_i][2:] if analytic else None, requires_reg=self._product_requires_regression(p))
+                self._member_rec[p_i] = rec
         # ---- phase B: the event array, class by class ----------------------------------------------------------------------------
         n_cash = np.diff(cash_start)
         cf_begin = np.concatenate([[0], np.cumsum(n_cash + ev_len)])[:-1]
@@ -434,10 +462,15 @@ class SimulationController:
     def _regression_schedule(self, p_i: int, product: Product):
         """backward list of (t_reg, roll_begin, roll_end, store_prod_idx|None, store_expo_idx|None).  Memoised on the
         product's timelines: books of thousands of products share a handful of distinct schedules."""
+        rec = self.__dict__.get("_member_rec", {}).get(p_i)          # products of one cash template share their timelines
+        if rec is not None and rec.get("sched") is not None:
+            return rec["sched"]
         pdates, preg = self._timelines(product)
         cache = self.__dict__.setdefault("_sched_cache", {})
         hit = cache.get((pdates, preg))
         if hit is not None:
+            if rec is not None:
+                rec["sched"] = hit
             return hit
         reg_tl = sorted(set(preg) | {float(t) for t in self.exposure_timeline})
         P = len(pdates)
@@ -455,6 +488,8 @@ class SimulationController:
                 last = t_next
             sched.append((t_reg, roll[0], roll[1], reg_pos.get(t_reg), self._exposure_time_to_idx.get(t_reg)))
         cache[(pdates, preg)] = sched
+        if rec is not None:
+            rec["sched"] = sched
         return sched
 
     def _regression_atoms(self, sched, asset_id):

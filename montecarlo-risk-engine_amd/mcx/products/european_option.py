@@ -11,6 +11,7 @@ from ..common.packages import FLOAT, device
 from ..models.black_scholes import BlackScholesModel
 from ..models.black_scholes_multi import BlackScholesMulti
 from ..request_interface.request_types import AtomicRequest, AtomicRequestType
+from .equity import Equity
 from .product import CashEvent, OptionType, Product, ProductFamily
 
 
@@ -44,9 +45,8 @@ class EuropeanOption(Product):
         """options on the spot of one asset with one maturity differ in strike and sign only: the controller builds their cash event
         (atoms, terms) once per key and re-uses it (books of 10^4-10^5 Europeans: pv_performance_large_netting_set.py).  None: no
         shortcut (any other underlying carries its own parameters)."""
-        from .equity import Equity
         und = self.underlying_requests[0].underlying_asset
-        return ("european", self._T, und.get_asset_id()) if type(und) is Equity else None
+        return (type(self).__name__, self._T, und.get_asset_id(), self.get_asset_id()) if type(und) is Equity else None
 
     def _cash_template_fill(self, row: tuple) -> tuple:
         return row[:8] + (float(self._K), float(self._sign())) + row[10:]
