@@ -141,7 +141,8 @@ def test_heston_qe_random_parameters_gpu_vs_oracle(smoothing, hip, oracle):
 def test_random_model_parameters_gpu_vs_oracle(hip, oracle):
     """paths of every model family and scheme on random parameter sets — strong / vanishing mean reversion, volatilities over three
     decades, correlations up to +-0.95, CIR++ starts a hair above zero, a four-asset BlackScholesMulti with a random correlation
-    matrix inside a ModelConfig with credit — against the oracle on identical Philox counters.  None of these steps contains a hard
+    matrix inside a ModelConfig with credit, Schwartz two-factor on a random curve, Hull-White on a random forward curve — against
+    the oracle on identical Philox counters.  None of these steps contains a hard
     indicator: the paths must agree entry by entry."""
     from mcx.common.enums import SimulationScheme as SS
     from mcx.engine.engine import MonteCarloEngine
@@ -172,7 +173,22 @@ def test_random_model_parameters_gpu_vs_oracle(hip, oracle):
         corr = 0.5 * np.eye(4) + 0.5 * c / np.outer(d, d)                                # (well inside the positive-definite cone: a credit column is added)
         return BlackScholesMulti(0.0, float(rng.uniform(0.0, 0.06)), ids, [lu(10.0, 500.0) for _ in ids], [lu(0.02, 0.9) for _ in ids], corr)
 
+    def s2f():
+        from mcx.models.schwartz_two_factor import SchwartzTwoFactorModel
+        ts = [0.0, 0.5, 1.0, 2.0, 5.0, 25.0]
+        return SchwartzTwoFactorModel(0.0, ts, [lu(10.0, 90.0) for _ in ts], rate=float(rng.uniform(0.0, 0.06)), short_term_mean_reversion=lu(1e-3, 5.0),
+                                      short_term_vol=lu(0.02, 0.8), long_term_drift=float(rng.uniform(-0.05, 0.05)), long_term_vol=lu(0.01, 0.4),
+                                      rho=float(rng.uniform(-0.9, 0.9)))
+
+    def hw():
+        from mcx.models.hull_white import HullWhiteModel
+        ts = np.linspace(0.0, 25.0, 26)
+        f = 0.03 + 0.02 * np.sin(ts / float(rng.uniform(2.0, 9.0))) + float(rng.uniform(-0.01, 0.02))
+        return HullWhiteModel(0.0, float(f[0]), list(f), list(np.gradient(f, ts)), lu(1e-2, 2.0), lu(1e-3, 0.05), curve_times=list(ts))
+
     builders = [
+        ("s2f", s2f, (SS.ANALYTICAL, SS.EULER)),
+        ("hull_white", hw, (SS.ANALYTICAL, SS.EULER)),
         ("bs", lambda: BlackScholesModel(0, lu(1.0, 1e3), float(rng.uniform(-0.02, 0.1)), lu(0.01, 1.5)), (SS.ANALYTICAL, SS.EULER)),
         ("vasicek", lambda: vas(), (SS.ANALYTICAL, SS.EULER)),
         ("cirpp", cir, (SS.EULER,)),
@@ -592,6 +608,44 @@ def test_exercise_products_take_the_forward_mode_path(hip):
             assert np.all(np.abs(a - b) <= 2e-6 * scale + 1e-9), (ns_i, m_i, a, b)
 
 
+def _random_exercise_book(case):
+    """a random Bermudan swaption on Vasicek (even cases) or American option on Black-Scholes (odd cases) with its exposure timeline"""
+    from mcx.products.swap import InterestRateSwap, IRSType
+    r = np.random.default_rng(300 + case)
+    if case % 2 == 0:
+        model = cases.VasicekModel(0.0, float(r.uniform(0.01, 0.05)), float(r.uniform(0.01, 0.07)), float(10 ** r.uniform(-1.5, 0)), float(10 ** r.uniform(-2.5, -1.6)))
+        mat = float(r.choice([2.0, 3.0, 4.0]))
+        und = InterestRateSwap(0.0, mat, 1.0, float(r.uniform(0.02, 0.05)), 0.25, 0.25, IRSType.PAYER if r.integers(0, 2) else IRSType.RECEIVER)
+        n_ex = int(r.integers(4, 12))
+        prod = cases.BermudanOption(und, [float(t) for t in np.linspace(mat / (n_ex + 1), mat * n_ex / (n_ex + 1), n_ex)], 0.0, cases.OptionType.CALL)
+        tl = np.linspace(0.0, mat, 9)
+    else:
+        model = cases.BlackScholesModel(0.0, float(r.uniform(80, 120)), float(r.uniform(0.0, 0.06)), float(r.uniform(0.15, 0.6)))
+        mat = float(r.choice([1.0, 2.0, 3.0]))
+        prod = cases.AmericanOption(cases.Equity("id"), mat, int(r.integers(4, 13)), float(r.uniform(85, 115)),
+                                    cases.OptionType.PUT if r.integers(0, 2) else cases.OptionType.CALL)
+        tl = np.linspace(0.0, mat, 7)
+    return prod, model, tl
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "unfused"])
+@pytest.mark.parametrize("case", [0, 1, 2, 3, 4, 5])
+def test_random_exercise_products_gpu_vs_oracle(case, fused, hip, oracle):
+    """random Bermudan swaptions / American options through the LSM, the exercise date programs of the one-launch kernel (or the event
+    interpreter) and the order-statistics select: EPE, PFE(0.95), ENE and PV against the oracle on identical counters.  An exercise
+    decision is a hard comparison of two numbers that agree to ~1e-15: at 16,384 paths no path should sit that close to its boundary."""
+    out = {}
+    for be in (hip, oracle):
+        prod, model, tl = _random_exercise_book(case)
+        rm = cases.RiskMetrics([cases.EPEMetric(), cases.PFEMetric(0.95), cases.ENEMetric(), cases.PVMetric()], exposure_timeline=tl)
+        sc = cases.SimulationController([cases.NettingSet(name="ex", products=[prod])], model, rm, 16384, 8192, 2, cases.E, backend=be)
+        if be is hip:
+            sc.allow_fused = fused
+        out[be.name] = [np.array(m, dtype=np.float64) for m in sc.run_simulation().results[0]]
+    for m_i, (a, b) in enumerate(zip(out["hip"], out["oracle"])):
+        assert np.allclose(a[:, 0], b[:, 0], rtol=1e-8, atol=1e-10), (case, m_i, a[:, 0], b[:, 0])
+
+
 @pytest.mark.parametrize("case", [0, 1, 2, 3])
 def test_forward_mode_through_random_exercise_products_against_replayed_bumps(case, hip):
     """random Bermudan swaptions (Vasicek) and American options (Black-Scholes): every EPE / ENE / PV sensitivity of the ONE forward-mode
@@ -599,23 +653,9 @@ def test_forward_mode_through_random_exercise_products_against_replayed_bumps(ca
     run's decisions — the derivative the reference's tape defines (bermudan_option.py:122-128)"""
     import mcx.aad as aad
     from mcx.helpers.host_threads import single_threaded_host
-    from mcx.products.swap import InterestRateSwap, IRSType
 
     def build():
-        r = np.random.default_rng(300 + case)
-        if case % 2 == 0:
-            model = cases.VasicekModel(0.0, float(r.uniform(0.01, 0.05)), float(r.uniform(0.01, 0.07)), float(10 ** r.uniform(-1.5, 0)), float(10 ** r.uniform(-2.5, -1.6)))
-            mat = float(r.choice([2.0, 3.0, 4.0]))
-            und = InterestRateSwap(0.0, mat, 1.0, float(r.uniform(0.02, 0.05)), 0.25, 0.25, IRSType.PAYER if r.integers(0, 2) else IRSType.RECEIVER)
-            n_ex = int(r.integers(4, 12))
-            prod = cases.BermudanOption(und, [float(t) for t in np.linspace(mat / (n_ex + 1), mat * n_ex / (n_ex + 1), n_ex)], 0.0, cases.OptionType.CALL)
-            tl = np.linspace(0.0, mat, 9)
-        else:
-            model = cases.BlackScholesModel(0.0, float(r.uniform(80, 120)), float(r.uniform(0.0, 0.06)), float(r.uniform(0.15, 0.6)))
-            mat = float(r.choice([1.0, 2.0, 3.0]))
-            prod = cases.AmericanOption(cases.Equity("id"), mat, int(r.integers(4, 13)), float(r.uniform(85, 115)),
-                                        cases.OptionType.PUT if r.integers(0, 2) else cases.OptionType.CALL)
-            tl = np.linspace(0.0, mat, 7)
+        prod, model, tl = _random_exercise_book(case)
         mets = [cases.EPEMetric(), cases.ENEMetric(), cases.PVMetric()]
         return [cases.NettingSet(name="ex", products=[prod])], model, cases.RiskMetrics(mets, exposure_timeline=tl)
 
